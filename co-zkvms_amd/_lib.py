@@ -1,0 +1,87 @@
+"""ctypes loader for libcozk.so (the HIP engine behind include/cozk.h).
+
+There is deliberately NO CPU fallback: if the shared library is missing, or no MI355X is visible
+when a context is created, the product path raises.  (The CPU restatement under oracle/ is test
+infrastructure and is never imported from here.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libcozk.so")
+
+OK = 0
+ERR_NO_DEVICE = -5
+
+SCALAR_FR, SCALAR_U8, SCALAR_U16, SCALAR_U32, SCALAR_U64, SCALAR_I64 = range(6)
+LOW_TO_HIGH, HIGH_TO_LOW = 0, 1
+MODE_PLAIN, MODE_REP3 = 1, 2
+OP_ADD, OP_SUB, OP_MUL = 0, 1, 2
+
+
+class CozkError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"cozk error {code}: {msg}")
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    """Load libcozk.so once; raise loudly when it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+        _lib = ctypes.CDLL(LIB_PATH)
+        _declare(_lib)
+    return _lib
+
+
+_vp = ctypes.c_void_p
+_sz = ctypes.c_size_t
+_i = ctypes.c_int
+_u64 = ctypes.c_uint64
+_pp = ctypes.POINTER(ctypes.c_void_p)
+
+# name -> (restype, argtypes); also the list the symbol-export test checks against include/cozk.h
+SIGNATURES = {
+    "cozk_device_count": (_i, [ctypes.POINTER(_i)]),
+    "cozk_ctx_create": (_i, [_i, _pp]),
+    "cozk_ctx_destroy": (_i, [_vp]),
+    "cozk_last_error": (ctypes.c_char_p, [_vp]),
+    "cozk_ctx_synchronize": (_i, [_vp]),
+    "cozk_ctx_stream": (_i, [_vp, _pp]),
+    "cozk_vec_upload": (_i, [_vp, _vp, _sz, _i, _pp]),
+    "cozk_vec_alloc": (_i, [_vp, _sz, _i, _pp]),
+    "cozk_vec_download": (_i, [_vp, _vp, _vp]),
+    "cozk_vec_free": (_i, [_vp]),
+    "cozk_vec_len": (_sz, [_vp]),
+    "cozk_vec_device_ptr": (_vp, [_vp]),
+    "cozk_vec_fill_random": (_i, [_vp, _vp, _u64, _i]),
+    "cozk_vec_binop": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "cozk_bases_upload": (_i, [_vp, _vp, _vp, _sz, _i, _pp]),
+    "cozk_bases_from_scalars": (_i, [_vp, _vp, _vp, _i, _pp]),
+    "cozk_bases_download": (_i, [_vp, _vp, _sz, _sz, _vp, _vp]),
+    "cozk_bases_free": (_i, [_vp]),
+    "cozk_bases_len": (_sz, [_vp]),
+    "cozk_bases_pair_sums": (_i, [_vp, _vp, _i, _pp]),
+    "cozk_msm": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp, ctypes.POINTER(_i)]),
+    "cozk_msm_vec": (_i, [_vp, _vp, _sz, _vp, _vp, ctypes.POINTER(_i)]),
+    "cozk_batch_msm_vec": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "cozk_g1_sum": (_i, [_vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_i)]),
+    "cozk_g1_mul": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_i)]),
+    "cozk_prof_enable": (_i, [_vp, _i]),
+    "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
+    "cozk_bench_montmul": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(ctypes.c_double)]),
+}
+
+
+def _declare(l):
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(l, name)
+        fn.restype = res
+        fn.argtypes = args

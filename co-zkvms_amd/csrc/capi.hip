@@ -1,0 +1,260 @@
+// libcozk C ABI: context, device vectors, synthetic data, micro-benchmarks.
+#include "common.hpp"
+
+// ------------------------------------------------------------------ synthetic data
+static __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// element i draws from its own SplitMix64 stream seeded with seed + i * 0xD1342543DE82EF95
+// (oracle/pyref.py `synthetic_fr` restates this).  FR: rejection-sample a canonical value < r
+// (top word masked to 62 bits), optionally masked to max_bits, stored in Montgomery form.
+__global__ void k_fill_random_fr(fe* out, size_t n, uint64_t seed, int max_bits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + (uint64_t)i * 0xD1342543DE82EF95ull;
+    fe v;
+    for (;;) {
+        uint64_t w0 = splitmix_next(s), w1 = splitmix_next(s), w2 = splitmix_next(s);
+        uint64_t w3 = splitmix_next(s) & ((1ull << 62) - 1ull);
+        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
+        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
+        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
+        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
+        if (!Fr::geq_mod(v)) break;
+    }
+    if (max_bits > 0 && max_bits < 254) {
+        for (int k = 0; k < 8; k++) {
+            int lo = 32 * k;
+            if (max_bits <= lo) v.l[k] = 0;
+            else if (max_bits < lo + 32) v.l[k] &= (1u << (max_bits - lo)) - 1u;
+        }
+    }
+    fe_store(out + i, Fr::to_mont(v));
+}
+
+template <class T>
+__global__ void k_fill_random_small(T* out, size_t n, uint64_t seed, int max_bits) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t s = seed + (uint64_t)i * 0xD1342543DE82EF95ull;
+    uint64_t v = splitmix_next(s);
+    int bits = (int)sizeof(T) * 8;
+    if (max_bits > 0 && max_bits < bits) bits = max_bits;
+    if (bits < 64) v &= (1ull << bits) - 1ull;
+    out[i] = (T)v;
+}
+
+// ------------------------------------------------------------------ element-wise field ops
+template <class F, int OP>
+__global__ void __launch_bounds__(256) k_fe_binop(const fe* __restrict__ a, const fe* __restrict__ b, fe* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe x = fe_load(a + i), y = fe_load(b + i), r;
+    if (OP == COZK_OP_ADD) r = F::add(x, y);
+    else if (OP == COZK_OP_SUB) r = F::sub(x, y);
+    else r = F::mul(x, y);
+    fe_store(out + i, r);
+}
+
+template <class F>
+static void launch_binop(cozk_ctx* ctx, int op, const fe* a, const fe* b, fe* out, size_t n) {
+    unsigned grid = (unsigned)((n + 255) / 256);
+    switch (op) {
+        case COZK_OP_ADD: k_fe_binop<F, COZK_OP_ADD><<<grid, 256, 0, ctx->stream>>>(a, b, out, n); break;
+        case COZK_OP_SUB: k_fe_binop<F, COZK_OP_SUB><<<grid, 256, 0, ctx->stream>>>(a, b, out, n); break;
+        case COZK_OP_MUL: k_fe_binop<F, COZK_OP_MUL><<<grid, 256, 0, ctx->stream>>>(a, b, out, n); break;
+        default: throw CozkError(COZK_ERR_INVALID_ARG, "unknown field op");
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+// ------------------------------------------------------------------ mont-mul micro benchmark
+template <int VARIANT>
+__global__ void __launch_bounds__(256) k_bench_montmul(fe* x, int iters) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    fe a = fe_load(x + i);
+    fe b = a;
+    b.l[0] ^= 0x5a5a5a5au & 0x0fffffffu;
+    if (VARIANT == 0) {
+        for (int k = 0; k < iters; k++) a = Fq::mul(a, b);
+    } else {
+        // two independent chains (ILP probe)
+        fe c = b;
+        for (int k = 0; k < iters; k += 2) {
+            a = Fq::mul(a, b);
+            c = Fq::mul(c, b);
+        }
+        a = Fq::add(a, c);
+    }
+    fe_store(x + i, a);
+}
+
+extern "C" {
+
+int cozk_device_count(int* out) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        if (out) *out = 0;
+        return COZK_ERR_NO_DEVICE;
+    }
+    if (out) *out = n;
+    return COZK_OK;
+}
+
+int cozk_ctx_create(int device, cozk_ctx** out) {
+    if (!out) return COZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return COZK_ERR_NO_DEVICE;  // no CPU fallback exists
+    if (device < 0 || device >= n) return COZK_ERR_INVALID_ARG;
+    cozk_ctx* ctx = new cozk_ctx();
+    ctx->device = device;
+    int rc = cozk_guard(ctx, [&] { HIP_TRY(hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)); });
+    if (rc != COZK_OK) {
+        delete ctx;
+        return rc;
+    }
+    *out = ctx;
+    return COZK_OK;
+}
+
+int cozk_ctx_destroy(cozk_ctx* ctx) {
+    if (!ctx) return COZK_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& pr : ctx->prof_events) {
+        (void)hipEventDestroy(pr.first);
+        (void)hipEventDestroy(pr.second);
+    }
+    ctx->msm_ws.release();
+    ctx->scratch.release();
+    ctx->scratch2.release();
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return COZK_OK;
+}
+
+const char* cozk_last_error(cozk_ctx* ctx) { return ctx ? ctx->last_error.c_str() : "null context"; }
+
+int cozk_ctx_synchronize(cozk_ctx* ctx) {
+    return cozk_guard(ctx, [&] { HIP_TRY(hipStreamSynchronize(ctx->stream)); });
+}
+
+int cozk_ctx_stream(cozk_ctx* ctx, void** out_stream) {
+    if (!ctx || !out_stream) return COZK_ERR_INVALID_ARG;
+    *out_stream = (void*)ctx->stream;
+    return COZK_OK;
+}
+
+int cozk_vec_alloc(cozk_ctx* ctx, size_t n, int kind, cozk_vec** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out && scalar_kind_bytes(kind), "vec_alloc: bad argument");
+        size_t bytes = n * scalar_kind_bytes(kind);
+        void* d = nullptr;
+        HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+        *out = new cozk_vec{ctx, n, kind, d, bytes, true};
+    });
+}
+
+int cozk_vec_upload(cozk_ctx* ctx, const void* host, size_t n, int kind, cozk_vec** out) {
+    int rc = cozk_vec_alloc(ctx, n, kind, out);
+    if (rc != COZK_OK) return rc;
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(host || n == 0, "vec_upload: null host pointer");
+        if ((*out)->bytes) {
+            HIP_TRY(hipMemcpyAsync((*out)->d, host, (*out)->bytes, hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    });
+}
+
+int cozk_vec_download(cozk_ctx* ctx, const cozk_vec* v, void* host) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && v && (host || v->bytes == 0), "vec_download: bad argument");
+        if (v->bytes) {
+            HIP_TRY(hipMemcpyAsync(host, v->d, v->bytes, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    });
+}
+
+int cozk_vec_free(cozk_vec* v) {
+    if (!v) return COZK_OK;
+    if (v->owned && v->d) (void)hipFree(v->d);
+    delete v;
+    return COZK_OK;
+}
+
+size_t cozk_vec_len(const cozk_vec* v) { return v ? v->n : 0; }
+void* cozk_vec_device_ptr(const cozk_vec* v) { return v ? v->d : nullptr; }
+
+int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && v, "vec_fill_random: bad argument");
+        if (v->n == 0) return;
+        unsigned grid = (unsigned)((v->n + 255) / 256);
+        switch (v->kind) {
+            case COZK_SCALAR_FR:
+                k_fill_random_fr<<<grid, 256, 0, ctx->stream>>>((fe*)v->d, v->n, seed, max_bits);
+                break;
+            case COZK_SCALAR_U8:
+                k_fill_random_small<uint8_t><<<grid, 256, 0, ctx->stream>>>((uint8_t*)v->d, v->n, seed, max_bits);
+                break;
+            case COZK_SCALAR_U16:
+                k_fill_random_small<uint16_t><<<grid, 256, 0, ctx->stream>>>((uint16_t*)v->d, v->n, seed, max_bits);
+                break;
+            case COZK_SCALAR_U32:
+                k_fill_random_small<uint32_t><<<grid, 256, 0, ctx->stream>>>((uint32_t*)v->d, v->n, seed, max_bits);
+                break;
+            default:
+                k_fill_random_small<uint64_t><<<grid, 256, 0, ctx->stream>>>((uint64_t*)v->d, v->n, seed, max_bits);
+                break;
+        }
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+int cozk_vec_binop(cozk_ctx* ctx, int op, int base_field, const cozk_vec* a, const cozk_vec* b, cozk_vec* out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && a && b && out && a->kind == COZK_SCALAR_FR && b->kind == COZK_SCALAR_FR &&
+                         out->kind == COZK_SCALAR_FR && a->n == b->n && a->n == out->n,
+                     "vec_binop: bad argument");
+        if (a->n == 0) return;
+        if (base_field) launch_binop<Fq>(ctx, op, (const fe*)a->d, (const fe*)b->d, (fe*)out->d, a->n);
+        else launch_binop<Fr>(ctx, op, (const fe*)a->d, (const fe*)b->d, (fe*)out->d, a->n);
+    });
+}
+
+int cozk_bench_montmul(cozk_ctx* ctx, size_t lanes, int iters, int variant, double* out_ms) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out_ms && lanes >= 256 && lanes % 256 == 0 && iters > 0, "bench_montmul: bad argument");
+        ctx->scratch2.reserve(lanes * sizeof(fe));
+        fe* x = ctx->scratch2.as<fe>();
+        k_fill_random_fr<<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, lanes, 12345, 0);
+        hipEvent_t e0, e1;
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        // warm-up launch, then the timed one
+        if (variant == 0) k_bench_montmul<0><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, 8);
+        else k_bench_montmul<1><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, 8);
+        HIP_TRY(hipEventRecord(e0, ctx->stream));
+        if (variant == 0) k_bench_montmul<0><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, iters);
+        else k_bench_montmul<1><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, iters);
+        HIP_TRY(hipEventRecord(e1, ctx->stream));
+        HIP_TRY(hipEventSynchronize(e1));
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, e0, e1));
+        *out_ms = ms;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+    });
+}
+
+}  // extern "C"

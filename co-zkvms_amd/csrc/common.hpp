@@ -1,0 +1,133 @@
+// Shared host-side plumbing for libcozk: context, error handling, device buffers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <stdexcept>
+
+#include "../../include/cozk.h"
+#include "ec.cuh"
+
+struct CozkError : std::runtime_error {
+    int code;
+    CozkError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+
+#define HIP_TRY(expr)                                                                          \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            char buf_[512];                                                                    \
+            snprintf(buf_, sizeof buf_, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                     __FILE__, __LINE__);                                                      \
+            throw CozkError(e_ == hipErrorOutOfMemory ? COZK_ERR_OOM : COZK_ERR_HIP, buf_);    \
+        }                                                                                      \
+    } while (0)
+
+#define COZK_REQUIRE(cond, msg)                                   \
+    do {                                                          \
+        if (!(cond)) throw CozkError(COZK_ERR_INVALID_ARG, msg);  \
+    } while (0)
+
+// A growable device scratch buffer (never shrinks; freed with the context).
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    void reserve(size_t bytes) {
+        if (bytes <= cap) return;
+        if (p) HIP_TRY(hipFree(p));
+        p = nullptr;
+        cap = 0;
+        HIP_TRY(hipMalloc(&p, bytes));
+        cap = bytes;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T>
+    T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct MsmWorkspace {
+    DevBuf hist, off0, refs, offA, offB, partA, partB, bsum, chunk, grp, out, ptrs;
+    void release() {
+        for (DevBuf* b : {&hist, &off0, &refs, &offA, &offB, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs})
+            b->release();
+    }
+};
+
+struct cozk_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    MsmWorkspace msm_ws;
+    DevBuf scratch;       // small reductions (round evaluations, block partials)
+    DevBuf scratch2;
+    void* pinned = nullptr;  // pinned host staging for small D2H results
+    size_t pinned_cap = 0;
+    // timing of the dominant kernel (bench roofline): accumulated HIP-event time of the
+    // bucket-accumulation launches on this stream
+    bool prof_enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> prof_events;
+    double prof_ms = 0.0;
+    uint64_t prof_launches = 0;
+    uint64_t prof_units = 0;  // point additions issued by those launches
+};
+
+struct cozk_bases {
+    cozk_ctx* ctx;
+    size_t n;           // number of SRS points
+    int nwin;           // 16 if a window table was precomputed, else 1
+    g1_affine* table;   // [nwin][n]: table[w][i] = 2^(16 w) * G_i   (table[0] = the points themselves)
+};
+
+struct cozk_vec {       // device array of field elements / small scalars
+    cozk_ctx* ctx;
+    size_t n;           // element count
+    int kind;           // COZK_SCALAR_*
+    void* d;            // device pointer
+    size_t bytes;
+    bool owned;
+};
+
+static inline size_t scalar_kind_bytes(int kind) {
+    switch (kind) {
+        case COZK_SCALAR_FR: return 32;
+        case COZK_SCALAR_U8: return 1;
+        case COZK_SCALAR_U16: return 2;
+        case COZK_SCALAR_U32: return 4;
+        case COZK_SCALAR_U64: return 8;
+        case COZK_SCALAR_I64: return 8;
+        default: return 0;
+    }
+}
+
+template <class F>
+static int cozk_guard(cozk_ctx* ctx, F&& f) {
+    try {
+        if (ctx) HIP_TRY(hipSetDevice(ctx->device));
+        f();
+        return COZK_OK;
+    } catch (const CozkError& e) {
+        if (ctx) ctx->last_error = e.what();
+        return e.code;
+    } catch (const std::exception& e) {
+        if (ctx) ctx->last_error = e.what();
+        return COZK_ERR_INTERNAL;
+    }
+}
+
+static inline void* ctx_pinned(cozk_ctx* ctx, size_t bytes) {
+    if (bytes > ctx->pinned_cap) {
+        if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+        ctx->pinned = nullptr;
+        size_t cap = bytes < 65536 ? 65536 : bytes;
+        HIP_TRY(hipHostMalloc(&ctx->pinned, cap, hipHostMallocDefault));
+        ctx->pinned_cap = cap;
+    }
+    return ctx->pinned;
+}

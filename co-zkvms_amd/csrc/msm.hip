@@ -1,0 +1,711 @@
+// Pippenger MSM over BN254 G1 for gfx950 -- the kernel set behind the MSM seam
+// (`VariableBaseMSM::{msm_field_elements, batch_msm}`; call sites
+// co-jolt/src/poly/commitment/pst13.rs:286-294,319-323,461-469,
+// co-noir-spartan/co-spartan/src/worker.rs:585,801-804).
+//
+// MI355X-first design (not a translation of jolt-core's rayon-over-windows CPU code):
+//   * 16-bit signed digits -> 2^15 buckets per group.  With a precomputed window table
+//     T[w][i] = 2^(16w) G_i (16 x n x 64 B, cheap in 288 GB of HBM) every window of every scalar
+//     lands in ONE bucket group per polynomial, so the per-window running-sum reductions and the
+//     Horner doublings disappear; without the table the 16 windows are 16 groups.
+//   * counting sort by bucket in HBM (histogram -> scan -> scatter of 4-byte point references);
+//     bucket order is arbitrary, which is fine because group addition commutes and all special
+//     cases (doubling / cancellation) are handled.
+//   * bucket accumulation = segmented reduction: one lane owns a segment of <= L consecutive
+//     sorted references and adds the gathered affine points into an XYZZ accumulator
+//     (8M+2S, no inversion).  Segments, not buckets, are the unit of parallelism, so skewed
+//     scalars (0/1 flags, u8/u16 witness columns: one bucket holding n/2 points) cost the same as
+//     uniform ones; further levels fold the per-segment partial sums until one value per bucket.
+//   * a batch of P polynomials is just P x more groups in the same launches (amortises the
+//     latency-bound bucket-reduction tail).
+// Results are returned as affine points, so the output is bit-exact to any correct MSM.
+#include "common.hpp"
+
+static constexpr uint32_t NB = 1u << 15;  // buckets per group
+static constexpr int CH = 16;             // buckets per reduction chunk
+static constexpr int TPB = 256;
+
+// ------------------------------------------------------------------ scalar -> signed digits
+template <int KIND>
+struct ScalarKind;
+template <>
+struct ScalarKind<COZK_SCALAR_FR> {
+    static constexpr int NWIN = 16;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        fe s = Fr::from_mont(fe_load(reinterpret_cast<const fe*>(p) + i));
+#pragma unroll
+        for (int k = 0; k < 8; k++) w[k] = s.l[k];
+        return false;
+    }
+};
+template <>
+struct ScalarKind<COZK_SCALAR_U8> {
+    static constexpr int NWIN = 1;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        w[0] = reinterpret_cast<const uint8_t*>(p)[i];
+        return false;
+    }
+};
+template <>
+struct ScalarKind<COZK_SCALAR_U16> {
+    static constexpr int NWIN = 2;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        w[0] = reinterpret_cast<const uint16_t*>(p)[i];
+        return false;
+    }
+};
+template <>
+struct ScalarKind<COZK_SCALAR_U32> {
+    static constexpr int NWIN = 3;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        w[0] = reinterpret_cast<const uint32_t*>(p)[i];
+        w[1] = 0;
+        return false;
+    }
+};
+template <>
+struct ScalarKind<COZK_SCALAR_U64> {
+    static constexpr int NWIN = 5;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        uint64_t v = reinterpret_cast<const uint64_t*>(p)[i];
+        w[0] = (uint32_t)v;
+        w[1] = (uint32_t)(v >> 32);
+        w[2] = 0;
+        return false;
+    }
+};
+template <>
+struct ScalarKind<COZK_SCALAR_I64> {
+    static constexpr int NWIN = 5;
+    static __device__ __forceinline__ bool load(const void* p, size_t i, uint32_t w[8]) {
+        int64_t v = reinterpret_cast<const int64_t*>(p)[i];
+        bool neg = v < 0;
+        uint64_t m = neg ? (uint64_t)0 - (uint64_t)v : (uint64_t)v;
+        w[0] = (uint32_t)m;
+        w[1] = (uint32_t)(m >> 32);
+        w[2] = 0;
+        return neg;
+    }
+};
+
+static inline int kind_nwin(int kind) {
+    switch (kind) {
+        case COZK_SCALAR_FR: return 16;
+        case COZK_SCALAR_U8: return 1;
+        case COZK_SCALAR_U16: return 2;
+        case COZK_SCALAR_U32: return 3;
+        default: return 5;
+    }
+}
+
+// Enumerate the non-zero signed digits of scalar i: calls f(window, bucket, negative).
+template <int KIND, class F>
+__device__ __forceinline__ void for_each_digit(const void* scalars, size_t i, F&& f) {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool neg = ScalarKind<KIND>::load(scalars, i, w);
+    uint32_t carry = 0;
+#pragma unroll
+    for (int k = 0; k < ScalarKind<KIND>::NWIN; k++) {
+        uint32_t v = ((w[k >> 1] >> (16 * (k & 1))) & 0xffffu) + carry;
+        bool sub = v > 32768u;
+        carry = sub ? 1u : 0u;
+        uint32_t mag = sub ? 65536u - v : v;
+        f(k, mag, sub != neg);
+    }
+}
+
+// counter[key] += 1 for every active lane; lanes that share the first active lane's key are
+// merged into one atomic (kills the single-hot-bucket contention of 0/1 and tiny-valued columns).
+static __device__ __forceinline__ uint32_t agg_atomic_add(uint32_t* counters, uint32_t key, bool active) {
+    uint64_t act = __ballot(active);
+    uint32_t pos = 0;
+    if (act == 0) return 0;
+    int lane = threadIdx.x & 63;
+    int first = __ffsll((unsigned long long)act) - 1;
+    uint32_t k0 = __shfl(key, first);
+    uint64_t same = __ballot(active && key == k0);
+    int cnt = __popcll(same);
+    bool merged = false;
+    if (cnt >= 4) {
+        uint32_t base = 0;
+        if (lane == first) base = atomicAdd(&counters[k0], (uint32_t)cnt);
+        base = __shfl(base, first);
+        if (active && key == k0) {
+            pos = base + __popcll(same & ((1ull << lane) - 1ull));
+            merged = true;
+        }
+    }
+    if (active && !merged) pos = atomicAdd(&counters[key], 1u);
+    return pos;
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(TPB) k_msm_hist(const void* scalars, size_t n, uint32_t* hist, int grouped) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    bool inr = i < n;
+    size_t ii = inr ? i : 0;
+    for_each_digit<KIND>(scalars, ii, [&](int k, uint32_t mag, bool) {
+        bool act = inr && mag != 0;
+        uint32_t key = (grouped ? (uint32_t)k * NB : 0u) + (mag - 1u);
+        agg_atomic_add(hist, act ? key : 0u, act);
+    });
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(TPB) k_msm_scatter(const void* scalars, size_t n, uint32_t* cursor, uint32_t* refs,
+                                                  int grouped, uint32_t table_n, uint32_t base_off) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    bool inr = i < n;
+    size_t ii = inr ? i : 0;
+    for_each_digit<KIND>(scalars, ii, [&](int k, uint32_t mag, bool negative) {
+        bool act = inr && mag != 0;
+        uint32_t key = (grouped ? (uint32_t)k * NB : 0u) + (mag - 1u);
+        uint32_t pos = agg_atomic_add(cursor, act ? key : 0u, act);
+        if (act) {
+            uint32_t ref = (grouped ? 0u : (uint32_t)k * table_n) + base_off + (uint32_t)ii;
+            refs[pos] = ref | (negative ? 0x80000000u : 0u);
+        }
+    });
+}
+
+// ------------------------------------------------------------------ scans (single block)
+// off[b] = exclusive prefix of cnt, off[nb] = total; cursor (optional) = copy of off[0..nb)
+template <bool FROM_OFFSETS>
+__global__ void __launch_bounds__(1024) k_scan(const uint32_t* in, uint32_t nb, uint32_t L, uint32_t* off,
+                                             uint32_t* cursor) {
+    __shared__ uint32_t sh[1024];
+    uint32_t tid = threadIdx.x;
+    uint32_t per = (nb + 1023u) / 1024u;
+    uint32_t b0 = tid * per, b1 = min(nb, b0 + per);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t c = FROM_OFFSETS ? (in[b + 1] - in[b] + L - 1u) / L : in[b];
+        sum += c;
+    }
+    sh[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? sh[tid - d] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - sum;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t c = FROM_OFFSETS ? (in[b + 1] - in[b] + L - 1u) / L : in[b];
+        off[b] = run;
+        if (cursor) cursor[b] = run;
+        run += c;
+    }
+    if (tid == 1023) off[nb] = sh[1023];
+}
+
+// largest b with off[b] <= t (buckets without segments are skipped automatically)
+static __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t nb, uint32_t t) {
+    uint32_t lo = 0, hi = nb;
+    while (hi - lo > 1) {
+        uint32_t mid = (lo + hi) >> 1;
+        if (off[mid] <= t) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// ------------------------------------------------------------------ bucket accumulation
+// level 0: gather affine SRS/table points by reference -- THE dominant kernel of the whole path
+__global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
+                                                 const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                                                 uint32_t nb, uint32_t L, g1_xyzz* __restrict__ out) {
+    uint32_t t = blockIdx.x * TPB + threadIdx.x;
+    uint32_t total = off_out[nb];
+    if (t >= total) return;
+    uint32_t b = find_bucket(off_out, nb, t);
+    uint32_t s = t - off_out[b];
+    uint32_t begin = off_in[b] + s * L;
+    uint32_t end = min(begin + L, off_in[b + 1]);
+    g1_xyzz acc = G1::identity();
+    for (uint32_t e = begin; e < end; e++) {
+        uint32_t ref = refs[e];
+        g1_affine p = affine_load(table + (ref & 0x7fffffffu));
+        if (ref >> 31) p.y = Fq::neg(p.y);
+        acc = G1::add_mixed(acc, p);
+    }
+    xyzz_store(out + t, acc);
+}
+
+// level >= 1: fold partial sums
+__global__ void __launch_bounds__(TPB) k_msm_accumN(const g1_xyzz* __restrict__ in, const uint32_t* __restrict__ off_in,
+                                                 const uint32_t* __restrict__ off_out, uint32_t nb, uint32_t L,
+                                                 g1_xyzz* __restrict__ out) {
+    uint32_t t = blockIdx.x * TPB + threadIdx.x;
+    uint32_t total = off_out[nb];
+    if (t >= total) return;
+    uint32_t b = find_bucket(off_out, nb, t);
+    uint32_t s = t - off_out[b];
+    uint32_t begin = off_in[b] + s * L;
+    uint32_t end = min(begin + L, off_in[b + 1]);
+    g1_xyzz acc = xyzz_load(in + begin);
+    for (uint32_t e = begin + 1; e < end; e++) acc = G1::add(acc, xyzz_load(in + e));
+    xyzz_store(out + t, acc);
+}
+
+// ------------------------------------------------------------------ bucket reduction: sum_k (k+1) B_k
+static __device__ __forceinline__ g1_xyzz bucket_value(const g1_xyzz* items, const uint32_t* off, uint32_t b) {
+    uint32_t o = off[b];
+    if (off[b + 1] > o) return xyzz_load(items + o);
+    return G1::identity();
+}
+
+__global__ void __launch_bounds__(TPB) k_msm_reduce_chunks(const g1_xyzz* __restrict__ items, const uint32_t* __restrict__ off,
+                                                        uint32_t ngroups, g1_xyzz* __restrict__ chunk_out) {
+    uint32_t t = blockIdx.x * TPB + threadIdx.x;
+    const uint32_t cpg = NB / CH;
+    if (t >= ngroups * cpg) return;
+    uint32_t g = t / cpg, c = t % cpg;
+    uint32_t k0 = c * CH;
+    g1_xyzz run = G1::identity(), acc = G1::identity();
+    for (int j = CH - 1; j >= 0; j--) {
+        run = G1::add(run, bucket_value(items, off, g * NB + k0 + (uint32_t)j));
+        acc = G1::add(acc, run);
+    }
+    // acc = sum_j (j+1) B_{k0+j};  add k0 * run with k0 = c << 4
+    if (c != 0 && !G1::is_identity(run)) {
+        g1_xyzz m = G1::identity();
+        for (int bit = 10; bit >= 0; bit--) {
+            m = G1::dbl(m);
+            if ((c >> bit) & 1u) m = G1::add(m, run);
+        }
+        for (int d = 0; d < 4; d++) m = G1::dbl(m);
+        acc = G1::add(acc, m);
+    }
+    xyzz_store(chunk_out + t, acc);
+}
+
+__global__ void __launch_bounds__(TPB) k_msm_reduce_groups(const g1_xyzz* __restrict__ chunk, g1_xyzz* __restrict__ grp) {
+    __shared__ g1_xyzz sh[TPB];
+    const uint32_t cpg = NB / CH;
+    uint32_t g = blockIdx.x, tid = threadIdx.x;
+    g1_xyzz acc = G1::identity();
+    for (uint32_t c = tid; c < cpg; c += TPB) acc = G1::add(acc, xyzz_load(chunk + (size_t)g * cpg + c));
+    sh[tid] = acc;
+    __syncthreads();
+    for (uint32_t s = TPB / 2; s > 0; s >>= 1) {
+        if (tid < s) {
+            acc = G1::add(acc, sh[tid + s]);
+            sh[tid] = acc;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) xyzz_store(grp + g, acc);
+}
+
+// Horner over the G window groups of each polynomial (G = 1 with a window table) + to_affine
+__global__ void k_msm_finalize(const g1_xyzz* __restrict__ grp, uint32_t G, uint32_t npoly, g1_affine* __restrict__ out) {
+    uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p >= npoly) return;
+    g1_xyzz acc = xyzz_load(grp + (size_t)p * G + (G - 1));
+    for (int w = (int)G - 2; w >= 0; w--) {
+        for (int d = 0; d < 16; d++) acc = G1::dbl(acc);
+        acc = G1::add(acc, xyzz_load(grp + (size_t)p * G + w));
+    }
+    affine_store(out + p, G1::to_affine(acc));
+}
+
+// ------------------------------------------------------------------ SRS kernels
+// table[w][i] = 2^16 * table[w-1][i]
+__global__ void __launch_bounds__(TPB) k_precompute_window(const g1_affine* __restrict__ prev, g1_affine* __restrict__ next, size_t n) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    g1_xyzz acc = G1::dbl_affine(affine_load(prev + i));
+    for (int d = 1; d < 16; d++) acc = G1::dbl(acc);
+    affine_store(next + i, G1::to_affine(acc));
+}
+
+// out[i] = s_i * g  (fixed-base, double-and-add)
+__global__ void __launch_bounds__(TPB) k_fixed_base_mul(const fe* __restrict__ scalars, g1_affine g, g1_affine* __restrict__ out, size_t n) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    fe s = Fr::from_mont(fe_load(scalars + i));
+    g1_xyzz acc = G1::identity();
+    for (int k = 7; k >= 0; k--) {
+        uint32_t w = s.l[k];
+        for (int b = 31; b >= 0; b--) {
+            acc = G1::dbl(acc);
+            if ((w >> b) & 1u) acc = G1::add_mixed(acc, g);
+        }
+    }
+    affine_store(out + i, G1::to_affine(acc));
+}
+
+__global__ void __launch_bounds__(TPB) k_pair_sums(const g1_affine* __restrict__ in, g1_affine* __restrict__ out, size_t nout) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= nout) return;
+    g1_xyzz acc = G1::from_affine(affine_load(in + 2 * i));
+    acc = G1::add_mixed(acc, affine_load(in + 2 * i + 1));
+    affine_store(out + i, G1::to_affine(acc));
+}
+
+// ------------------------------------------------------------------ host orchestration
+static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
+
+static void build_window_table(cozk_ctx* ctx, cozk_bases* b) {
+    for (int w = 1; w < b->nwin; w++) {
+        k_precompute_window<<<cdiv(b->n, TPB), TPB, 0, ctx->stream>>>(b->table + (size_t)(w - 1) * b->n,
+                                                                     b->table + (size_t)w * b->n, b->n);
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+template <int KIND>
+static void launch_hist(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* hist, int grouped) {
+    k_msm_hist<KIND><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(sc, n, hist, grouped);
+}
+template <int KIND>
+static void launch_scatter(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* cursor, uint32_t* refs, int grouped,
+                           uint32_t table_n, uint32_t base_off) {
+    k_msm_scatter<KIND><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(sc, n, cursor, refs, grouped, table_n, base_off);
+}
+
+#define KIND_DISPATCH(kind, CALL)                                              \
+    switch (kind) {                                                            \
+        case COZK_SCALAR_FR: { constexpr int K = COZK_SCALAR_FR; CALL; } break;   \
+        case COZK_SCALAR_U8: { constexpr int K = COZK_SCALAR_U8; CALL; } break;   \
+        case COZK_SCALAR_U16: { constexpr int K = COZK_SCALAR_U16; CALL; } break; \
+        case COZK_SCALAR_U32: { constexpr int K = COZK_SCALAR_U32; CALL; } break; \
+        case COZK_SCALAR_U64: { constexpr int K = COZK_SCALAR_U64; CALL; } break; \
+        case COZK_SCALAR_I64: { constexpr int K = COZK_SCALAR_I64; CALL; } break; \
+        default: throw CozkError(COZK_ERR_INVALID_ARG, "unknown scalar kind");    \
+    }
+
+// P MSMs over bases[offset .. offset+n); scalars[p] device pointers of kinds[p]; results -> d_out[P]
+void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_t n, const void* const* scalars,
+                    const int* kinds, size_t P, g1_affine* d_out) {
+    COZK_REQUIRE(offset + n <= bases->n, "msm: base slice out of range");
+    COZK_REQUIRE(P >= 1, "msm: empty batch");
+    COZK_REQUIRE((uint64_t)bases->n * (uint64_t)bases->nwin < (1ull << 31), "msm: table too large for 31-bit refs");
+    MsmWorkspace& ws = ctx->msm_ws;
+    hipStream_t st = ctx->stream;
+    if (n == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, P * sizeof(g1_affine), st));
+        return;
+    }
+    const bool pre = bases->nwin == 16;
+    const uint32_t G = pre ? 1u : 16u;
+    const uint32_t ngroups = (uint32_t)P * G;
+    const uint32_t nb = ngroups * NB;
+    uint64_t M = 0, bound = 0;
+    for (size_t p = 0; p < P; p++) {
+        uint64_t m = (uint64_t)n * kind_nwin(kinds[p]);
+        M += m;
+        if (m > bound) bound = m;
+    }
+    COZK_REQUIRE(M < (1ull << 32), "msm: batch too large (reference count exceeds 32 bits)");
+    // segment length of level 0: aim at >= ~2^18 lanes, clamp to [8, 64]
+    uint32_t L0 = (uint32_t)(M >> 18);
+    if (L0 < 8) L0 = 8;
+    if (L0 > 64) L0 = 64;
+    const uint32_t L1 = 32;
+
+    ws.hist.reserve((size_t)(nb + 1) * 4);
+    ws.off0.reserve((size_t)(nb + 1) * 4);
+    ws.offA.reserve((size_t)(nb + 1) * 4);
+    ws.offB.reserve((size_t)(nb + 1) * 4);
+    ws.refs.reserve((size_t)M * 4);
+    const uint64_t maxseg0 = M / L0 + nb;
+    // segment counts obey x_{k+1} = x_k / L1 + nb <= max(x_0, 2 nb): size both ping-pong buffers for that
+    const uint64_t maxpart = maxseg0 > 2ull * nb ? maxseg0 : 2ull * nb;
+    ws.partA.reserve((size_t)maxpart * sizeof(g1_xyzz));
+    ws.partB.reserve((size_t)maxpart * sizeof(g1_xyzz));
+    ws.chunk.reserve((size_t)ngroups * (NB / CH) * sizeof(g1_xyzz));
+    ws.grp.reserve((size_t)ngroups * sizeof(g1_xyzz));
+
+    uint32_t* hist = ws.hist.as<uint32_t>();
+    uint32_t* off0 = ws.off0.as<uint32_t>();
+    uint32_t* refs = ws.refs.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 1) * 4, st));
+    for (size_t p = 0; p < P; p++) {
+        uint32_t* h = hist + (size_t)p * G * NB;
+        KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], n, h, pre ? 0 : 1));
+    }
+    // hist doubles as the scatter cursor after the scan
+    k_scan<false><<<1, 1024, 0, st>>>(hist, nb, 1, off0, hist);
+    for (size_t p = 0; p < P; p++) {
+        uint32_t* cur = hist + (size_t)p * G * NB;
+        KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], n, cur, refs, pre ? 0 : 1, (uint32_t)bases->n,
+                                                  (uint32_t)offset));
+    }
+    // level 0
+    uint32_t* offA = ws.offA.as<uint32_t>();
+    uint32_t* offB = ws.offB.as<uint32_t>();
+    k_scan<true><<<1, 1024, 0, st>>>(off0, nb, L0, offA, nullptr);
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    if (ctx->prof_enabled) {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
+        HIP_TRY(hipEventRecord(e0, st));
+    }
+    k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
+    if (ctx->prof_enabled) {
+        HIP_TRY(hipEventRecord(e1, st));
+        ctx->prof_events.push_back({e0, e1});
+        ctx->prof_launches += 1;
+        ctx->prof_units += M;
+    }
+    // further levels until the worst case leaves one value per bucket
+    uint64_t cnt = (bound + L0 - 1) / L0;
+    uint64_t maxseg = maxseg0;
+    g1_xyzz* cur_items = ws.partA.as<g1_xyzz>();
+    g1_xyzz* nxt_items = ws.partB.as<g1_xyzz>();
+    uint32_t* cur_off = offA;
+    uint32_t* nxt_off = offB;
+    while (cnt > 1) {
+        uint64_t nseg = maxseg / L1 + nb;
+        k_scan<true><<<1, 1024, 0, st>>>(cur_off, nb, L1, nxt_off, nullptr);
+        k_msm_accumN<<<cdiv(nseg, TPB), TPB, 0, st>>>(cur_items, cur_off, nxt_off, nb, L1, nxt_items);
+        std::swap(cur_items, nxt_items);
+        std::swap(cur_off, nxt_off);
+        maxseg = nseg;
+        cnt = (cnt + L1 - 1) / L1;
+    }
+    k_msm_reduce_chunks<<<cdiv((uint64_t)ngroups * (NB / CH), TPB), TPB, 0, st>>>(cur_items, cur_off, ngroups,
+                                                                               ws.chunk.as<g1_xyzz>());
+    k_msm_reduce_groups<<<ngroups, TPB, 0, st>>>(ws.chunk.as<g1_xyzz>(), ws.grp.as<g1_xyzz>());
+    k_msm_finalize<<<cdiv(P, 64), 64, 0, st>>>(ws.grp.as<g1_xyzz>(), G, (uint32_t)P, d_out);
+    HIP_TRY(hipGetLastError());
+}
+
+// maximum polynomials per launch set: keeps refs (4 B x 16 n P) and partial sums inside a fixed budget
+static size_t msm_batch_limit(size_t n, bool pre) {
+    uint64_t per = (uint64_t)n * 16;
+    uint64_t lim = per ? (1ull << 28) / per : 8;  // <= 2^28 references (1 GiB of refs) per launch set
+    if (lim < 1) lim = 1;
+    if (lim > (pre ? 16u : 4u)) lim = pre ? 16u : 4u;
+    return (size_t)lim;
+}
+
+static void affine_to_abi(const g1_affine& a, uint64_t xy[8], int* inf) {
+    bool is_inf = G1::is_inf(a);
+    for (int i = 0; i < 4; i++) {
+        xy[i] = (uint64_t)a.x.l[2 * i] | ((uint64_t)a.x.l[2 * i + 1] << 32);
+        xy[4 + i] = (uint64_t)a.y.l[2 * i] | ((uint64_t)a.y.l[2 * i + 1] << 32);
+    }
+    if (inf) *inf = is_inf ? 1 : 0;
+}
+static g1_affine abi_to_affine(const uint64_t xy[8], int inf) {
+    g1_affine a;
+    for (int i = 0; i < 4; i++) {
+        a.x.l[2 * i] = (uint32_t)xy[i];
+        a.x.l[2 * i + 1] = (uint32_t)(xy[i] >> 32);
+        a.y.l[2 * i] = (uint32_t)xy[4 + i];
+        a.y.l[2 * i + 1] = (uint32_t)(xy[4 + i] >> 32);
+    }
+    if (inf) {
+        a.x = Fq::zero();
+        a.y = Fq::zero();
+    }
+    return a;
+}
+
+void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_t n, const void* const* scalars,
+               const int* kinds, size_t k, uint64_t* out_xy, int* out_inf) {
+    ctx->msm_ws.out.reserve(k * sizeof(g1_affine));
+    g1_affine* d_out = ctx->msm_ws.out.as<g1_affine>();
+    size_t lim = msm_batch_limit(n, bases->nwin == 16);
+    for (size_t s = 0; s < k; s += lim) {
+        size_t P = k - s < lim ? k - s : lim;
+        msm_run_device(ctx, bases, offset, n, scalars + s, kinds + s, P, d_out + s);
+    }
+    g1_affine* h = reinterpret_cast<g1_affine*>(ctx_pinned(ctx, k * sizeof(g1_affine)));
+    HIP_TRY(hipMemcpyAsync(h, d_out, k * sizeof(g1_affine), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < k; i++) affine_to_abi(h[i], out_xy + 8 * i, out_inf ? out_inf + i : nullptr);
+}
+
+// ------------------------------------------------------------------ C ABI
+extern "C" {
+
+int cozk_bases_upload(cozk_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n, int precompute,
+                      cozk_bases** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && xy && out && n > 0, "bases_upload: bad argument");
+        cozk_bases* b = new cozk_bases{ctx, n, precompute ? 16 : 1, nullptr};
+        try {
+            HIP_TRY(hipMalloc((void**)&b->table, (size_t)b->nwin * n * sizeof(g1_affine)));
+            std::vector<g1_affine> h(n);
+            for (size_t i = 0; i < n; i++) h[i] = abi_to_affine(xy + 8 * i, infinity ? infinity[i] : 0);
+            HIP_TRY(hipMemcpyAsync(b->table, h.data(), n * sizeof(g1_affine), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            build_window_table(ctx, b);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } catch (...) {
+            if (b->table) (void)hipFree(b->table);
+            delete b;
+            throw;
+        }
+        *out = b;
+    });
+}
+
+int cozk_bases_from_scalars(cozk_ctx* ctx, const cozk_vec* s, const uint64_t* g_xy, int precompute, cozk_bases** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && s && g_xy && out && s->kind == COZK_SCALAR_FR && s->n > 0, "bases_from_scalars: bad argument");
+        size_t n = s->n;
+        cozk_bases* b = new cozk_bases{ctx, n, precompute ? 16 : 1, nullptr};
+        try {
+            HIP_TRY(hipMalloc((void**)&b->table, (size_t)b->nwin * n * sizeof(g1_affine)));
+            g1_affine g = abi_to_affine(g_xy, 0);
+            k_fixed_base_mul<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(reinterpret_cast<const fe*>(s->d), g, b->table, n);
+            HIP_TRY(hipGetLastError());
+            build_window_table(ctx, b);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } catch (...) {
+            if (b->table) (void)hipFree(b->table);
+            delete b;
+            throw;
+        }
+        *out = b;
+    });
+}
+
+int cozk_bases_pair_sums(cozk_ctx* ctx, const cozk_bases* src, int precompute, cozk_bases** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && src && out && src->n >= 2 && src->n % 2 == 0, "bases_pair_sums: bad argument");
+        size_t n = src->n / 2;
+        cozk_bases* b = new cozk_bases{ctx, n, precompute ? 16 : 1, nullptr};
+        try {
+            HIP_TRY(hipMalloc((void**)&b->table, (size_t)b->nwin * n * sizeof(g1_affine)));
+            k_pair_sums<<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(src->table, b->table, n);
+            HIP_TRY(hipGetLastError());
+            build_window_table(ctx, b);
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        } catch (...) {
+            if (b->table) (void)hipFree(b->table);
+            delete b;
+            throw;
+        }
+        *out = b;
+    });
+}
+
+int cozk_bases_download(cozk_ctx* ctx, const cozk_bases* b, size_t offset, size_t n, uint64_t* xy, uint8_t* infinity) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && b && xy && offset + n <= b->n, "bases_download: bad argument");
+        std::vector<g1_affine> h(n);
+        HIP_TRY(hipMemcpyAsync(h.data(), b->table + offset, n * sizeof(g1_affine), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < n; i++) {
+            int inf;
+            affine_to_abi(h[i], xy + 8 * i, &inf);
+            if (infinity) infinity[i] = (uint8_t)inf;
+        }
+    });
+}
+
+int cozk_bases_free(cozk_bases* b) {
+    if (!b) return COZK_OK;
+    if (b->table) (void)hipFree(b->table);
+    delete b;
+    return COZK_OK;
+}
+
+size_t cozk_bases_len(const cozk_bases* b) { return b ? b->n : 0; }
+
+int cozk_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const cozk_vec* scalars, uint64_t out_xy[8],
+                 int* out_infinity) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && bases && scalars && out_xy, "msm_vec: bad argument");
+        const void* p = scalars->d;
+        int kind = scalars->kind;
+        msm_batch(ctx, bases, offset, scalars->n, &p, &kind, 1, out_xy, out_infinity);
+    });
+}
+
+int cozk_batch_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const cozk_vec* const* scalars, size_t k,
+                       uint64_t* out_xy, int* out_infinity) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && bases && scalars && out_xy && k > 0, "batch_msm_vec: bad argument");
+        std::vector<const void*> ptrs(k);
+        std::vector<int> kinds(k);
+        size_t n = scalars[0]->n;
+        for (size_t i = 0; i < k; i++) {
+            // "batch commit requires all batches to have the same length" (pst13.rs:310-313)
+            COZK_REQUIRE(scalars[i] && scalars[i]->n == n, "batch_msm_vec: polynomials must have equal length");
+            ptrs[i] = scalars[i]->d;
+            kinds[i] = scalars[i]->kind;
+        }
+        msm_batch(ctx, bases, offset, n, ptrs.data(), kinds.data(), k, out_xy, out_infinity);
+    });
+}
+
+int cozk_msm(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const void* host_scalars, int kind, size_t n,
+             uint64_t out_xy[8], int* out_infinity) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && bases && (host_scalars || n == 0) && out_xy && scalar_kind_bytes(kind), "msm: bad argument");
+        size_t bytes = n * scalar_kind_bytes(kind);
+        ctx->scratch2.reserve(bytes ? bytes : 16);
+        if (bytes) HIP_TRY(hipMemcpyAsync(ctx->scratch2.p, host_scalars, bytes, hipMemcpyHostToDevice, ctx->stream));
+        const void* p = ctx->scratch2.p;
+        msm_batch(ctx, bases, offset, n, &p, &kind, 1, out_xy, out_infinity);
+    });
+}
+
+int cozk_g1_sum(cozk_ctx* ctx, const uint64_t* xy, const int* infinity, size_t k, uint64_t out_xy[8], int* out_infinity) {
+    return cozk_guard(nullptr, [&] {
+        (void)ctx;
+        g1_xyzz acc = G1::identity();
+        for (size_t i = 0; i < k; i++) acc = G1::add_mixed(acc, abi_to_affine(xy + 8 * i, infinity ? infinity[i] : 0));
+        affine_to_abi(G1::to_affine(acc), out_xy, out_infinity);
+    });
+}
+
+int cozk_g1_mul(cozk_ctx* ctx, const uint64_t xy[8], int infinity, const uint64_t s[4], uint64_t out_xy[8], int* out_infinity) {
+    return cozk_guard(nullptr, [&] {
+        (void)ctx;
+        fe sm;
+        for (int i = 0; i < 4; i++) {
+            sm.l[2 * i] = (uint32_t)s[i];
+            sm.l[2 * i + 1] = (uint32_t)(s[i] >> 32);
+        }
+        fe sc = Fr::from_mont(sm);
+        g1_affine p = abi_to_affine(xy, infinity);
+        g1_xyzz acc = G1::identity();
+        for (int k = 7; k >= 0; k--)
+            for (int b = 31; b >= 0; b--) {
+                acc = G1::dbl(acc);
+                if ((sc.l[k] >> b) & 1u) acc = G1::add_mixed(acc, p);
+            }
+        affine_to_abi(G1::to_affine(acc), out_xy, out_infinity);
+    });
+}
+
+int cozk_prof_enable(cozk_ctx* ctx, int on) {
+    return cozk_guard(ctx, [&] {
+        ctx->prof_enabled = on != 0;
+        for (auto& pr : ctx->prof_events) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        ctx->prof_events.clear();
+        ctx->prof_ms = 0;
+        ctx->prof_launches = 0;
+        ctx->prof_units = 0;
+    });
+}
+
+int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds) {
+    return cozk_guard(ctx, [&] {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        for (auto& pr : ctx->prof_events) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            ctx->prof_ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        ctx->prof_events.clear();
+        if (launches) *launches = ctx->prof_launches;
+        if (total_ms) *total_ms = ctx->prof_ms;
+        if (point_adds) *point_adds = ctx->prof_units;
+    });
+}
+
+}  // extern "C"

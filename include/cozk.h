@@ -1,0 +1,144 @@
+/*
+ * cozk.h -- C ABI of libcozk, the MI355X-native engine for the sumcheck + polynomial-commitment
+ * hot path of ChainSafe/co-zkvms (co-jolt / co-noir-spartan workers).
+ *
+ * This is the drop-in boundary.  Every entry point names the reference interface
+ * it replaces (paths relative to the reference repository root).  Conventions:
+ *   - plain pointers and sizes only; no C++/torch types; every function returns an int status
+ *     (COZK_OK = 0, negative = error; never unwinds across the boundary);
+ *     cozk_last_error(ctx) returns the message of the last failure on that context.
+ *   - field elements: BN254 Fr / Fq as 4 x u64 little-endian limbs in MONTGOMERY form (R = 2^256),
+ *     i.e. the in-memory layout of arkworks `Fp256<MontBackend<_,4>>` (ark-ff 0.5).
+ *   - G1 points cross the boundary affine: x[4], y[4] (Fq Montgomery, 64 B) + infinity flag.
+ *   - one cozk_ctx per (party, GPU); a ctx owns one HIP stream and is NOT thread-safe -- mirror of
+ *     the single-owner IoContext forks (mpc-core/src/protocols/rep3/network.rs:108-119).
+ *   - handles (cozk_vec / cozk_bases / cozk_poly / cozk_layer / cozk_spliteq) are device resident;
+ *     only round messages (3-8 field elements), commitments and opening proofs cross PCIe.
+ */
+#ifndef COZK_H
+#define COZK_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define COZK_OK 0
+#define COZK_ERR_INVALID_ARG (-1)
+#define COZK_ERR_HIP (-2)
+#define COZK_ERR_OOM (-3)
+#define COZK_ERR_INTERNAL (-4)
+#define COZK_ERR_NO_DEVICE (-5)
+
+/* scalar kinds: the variants of jolt-core `MultilinearPolynomial` that
+ * `VariableBaseMSM::batch_msm` dispatches on (call site co-jolt/src/poly/commitment/pst13.rs:319-323) */
+#define COZK_SCALAR_FR 0  /* LargeScalars: Fr Montgomery, 32 B */
+#define COZK_SCALAR_U8 1  /* U8Scalars  (also 0/1 flags) */
+#define COZK_SCALAR_U16 2 /* U16Scalars */
+#define COZK_SCALAR_U32 3 /* U32Scalars */
+#define COZK_SCALAR_U64 4 /* U64Scalars */
+#define COZK_SCALAR_I64 5 /* I64Scalars */
+
+/* BindingOrder (jolt-core poly::multilinear_polynomial::BindingOrder; used
+ * co-jolt/src/poly/dense_mlpoly.rs:310-459) */
+#define COZK_LOW_TO_HIGH 0
+#define COZK_HIGH_TO_LOW 1
+
+/* share mode of a polynomial handle */
+#define COZK_MODE_PLAIN 1 /* one field element per entry (plain prover / public polynomial) */
+#define COZK_MODE_REP3 2  /* Rep3PrimeFieldShare {a, b}: mpc-types/src/protocols/rep3/arithmetic/types.rs:22-29 */
+
+typedef struct cozk_ctx cozk_ctx;
+typedef struct cozk_bases cozk_bases;
+typedef struct cozk_vec cozk_vec;
+
+/* ---------------------------------------------------------------- context ----------------- */
+/* replaces `icicle_init()` (co-jolt/examples/rep3_jolt.rs:195) + IoContext creation */
+int cozk_ctx_create(int device, cozk_ctx** out);
+int cozk_ctx_destroy(cozk_ctx* ctx);
+const char* cozk_last_error(cozk_ctx* ctx);
+int cozk_ctx_synchronize(cozk_ctx* ctx);
+/* raw hipStream_t of the context (so a host can order its own work / events against it) */
+int cozk_ctx_stream(cozk_ctx* ctx, void** out_stream);
+int cozk_device_count(int* out);
+
+/* ---------------------------------------------------------------- device vectors ---------- */
+/* upload a scalar vector (kind = COZK_SCALAR_*); `host` holds n elements of that kind */
+int cozk_vec_upload(cozk_ctx* ctx, const void* host, size_t n, int kind, cozk_vec** out);
+int cozk_vec_alloc(cozk_ctx* ctx, size_t n, int kind, cozk_vec** out);
+int cozk_vec_download(cozk_ctx* ctx, const cozk_vec* v, void* host);
+int cozk_vec_free(cozk_vec* v);
+size_t cozk_vec_len(const cozk_vec* v);
+/* raw device pointer (for zero-copy interop with the host's own device buffers, e.g. RCCL staging) */
+void* cozk_vec_device_ptr(const cozk_vec* v);
+/* synthetic data: element i draws from SplitMix64(seed + i * 0xD1342543DE82EF95): FR = canonical value
+ * rejection-sampled below r, stored in Montgomery form; small kinds = low bits.  max_bits > 0 masks
+ * the value to that many bits (e.g. 1 for 0/1 flags). */
+int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits);
+
+/* element-wise out[i] = a[i] (op) b[i] on 32-byte field elements: the local arithmetic of
+ * mpc-types/src/protocols/additive/ops.rs (AdditivePrimeFieldShare is repr(transparent) over F).
+ * base_field = 0: Fr (scalar field, what shares live in); 1: Fq (G1 coordinate field). */
+#define COZK_OP_ADD 0
+#define COZK_OP_SUB 1
+#define COZK_OP_MUL 2
+int cozk_vec_binop(cozk_ctx* ctx, int op, int base_field, const cozk_vec* a, const cozk_vec* b,
+                   cozk_vec* out);
+
+/* ---------------------------------------------------------------- MSM seam ---------------- */
+/* Upload SRS points (`ck.powers_of_g[i]`, co-jolt/src/poly/commitment/pst13.rs:286-287,461-462) once;
+ * replaces the ICICLE `gpu_bases: Option<&[GpuBaseType]>` argument (pst13.rs:52-59,288,320).
+ * xy = n x 8 u64 (x[4], y[4]); infinity = n bytes or NULL.  precompute != 0 additionally builds the
+ * window table 2^(16w) * G_i (16 x n x 64 B of HBM) that merges all Pippenger windows into one
+ * bucket set. */
+int cozk_bases_upload(cozk_ctx* ctx, const uint64_t* xy, const uint8_t* infinity, size_t n,
+                      int precompute, cozk_bases** out);
+/* bases[i] = scalars[i] * g on device -- `MultilinearPC::setup` building `powers_of_g`
+ * (ark-poly-commit, invoked by PST13::setup co-jolt/src/poly/commitment/pst13.rs:49-62).
+ * g_xy = affine generator (8 u64). */
+int cozk_bases_from_scalars(cozk_ctx* ctx, const cozk_vec* scalars_fr, const uint64_t* g_xy,
+                            int precompute, cozk_bases** out);
+int cozk_bases_download(cozk_ctx* ctx, const cozk_bases* b, size_t offset, size_t n, uint64_t* xy,
+                        uint8_t* infinity);
+int cozk_bases_free(cozk_bases* b);
+size_t cozk_bases_len(const cozk_bases* b);
+/* G'[b] = G[2b] + G[2b+1]: folds the duplicated scalars `q[k][x >> 1]` of PST13 `open`
+ * (pst13.rs:459) into a half-size MSM */
+int cozk_bases_pair_sums(cozk_ctx* ctx, const cozk_bases* b, int precompute, cozk_bases** out);
+
+/* `VariableBaseMSM::msm_field_elements(bases[offset..offset+n], _, scalars, _, _)`
+ * (call sites pst13.rs:286-294,461-469; co-noir-spartan/co-spartan/src/worker.rs:801-804).
+ * Host-scalar form (PCIe inclusive) and device-resident form. */
+int cozk_msm(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const void* host_scalars,
+             int kind, size_t n, uint64_t out_xy[8], int* out_infinity);
+int cozk_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const cozk_vec* scalars,
+                 uint64_t out_xy[8], int* out_infinity);
+/* `VariableBaseMSM::batch_msm(bases[..n], _, polys)` (pst13.rs:319-323): k MSMs over one base
+ * slice; out_xy = k x 8 u64, out_infinity = k ints. */
+int cozk_batch_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset,
+                       const cozk_vec* const* scalars, size_t k, uint64_t* out_xy,
+                       int* out_infinity);
+
+/* G1 helpers used by the coordinator-side combine (`combine_commitment_shares`, pst13.rs:72-108;
+ * `coordinate_prove`, :110-122): out = sum of k affine points */
+int cozk_g1_sum(cozk_ctx* ctx, const uint64_t* xy, const int* infinity, size_t k,
+                uint64_t out_xy[8], int* out_infinity);
+/* out = s * P (host helper for `combine_commitments`, pst13.rs:333-348, and trapdoor checks) */
+int cozk_g1_mul(cozk_ctx* ctx, const uint64_t xy[8], int infinity, const uint64_t s[4],
+                uint64_t out_xy[8], int* out_infinity);
+
+/* ---------------------------------------------------------------- profiling ---------------- */
+/* HIP-event timing of the dominant kernel (MSM bucket accumulation) on the ctx stream, for
+ * bench.py's roofline object: launches, total ms, point additions issued. */
+int cozk_prof_enable(cozk_ctx* ctx, int on);
+int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds);
+/* Fq Montgomery-multiply micro-benchmark: `iters` dependent products per lane on `lanes` lanes;
+ * returns elapsed ms (HIP events) -- the measured integer-ALU peak. */
+int cozk_bench_montmul(cozk_ctx* ctx, size_t lanes, int iters, int variant, double* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COZK_H */

@@ -1,0 +1,26 @@
+import importlib
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def cozk():
+    """the product package (directory name has a hyphen, hence importlib)"""
+    return importlib.import_module("co-zkvms_amd")
+
+
+@pytest.fixture(scope="session")
+def ctx(cozk):
+    c = cozk.Context(0)
+    yield c
+    c.close()

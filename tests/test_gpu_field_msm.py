@@ -1,0 +1,133 @@
+"""GPU parity: field arithmetic and the MSM seam against the exact big-int oracle (oracle/pyref.py).
+Bar: bit-exact (integer work).  Calls go through the C ABI (ctypes)."""
+import numpy as np
+import pytest
+
+import pyref as O
+
+pytestmark = pytest.mark.gpu
+
+EDGE = [0, 1, 2, O.R - 1, O.R - 2, O.R_MONT_ONE, (1 << 253) + 12345, (1 << 253) - 1, O.TWO_INV]
+
+
+def _rand_fr(rng, n, mod=O.R):
+    return [rng.field(mod) for _ in range(n)]
+
+
+@pytest.mark.parametrize("base_field", [False, True])
+def test_field_binops_bit_exact(cozk, ctx, base_field):
+    mod = O.P if base_field else O.R
+    rng = O.SplitMix64(11 + base_field)
+    edge = [e % mod for e in EDGE] + [mod - 1, mod - 2]
+    a = edge + _rand_fr(rng, 2000, mod)
+    b = list(reversed(edge)) + _rand_fr(rng, 2000, mod)
+    # values are uploaded as Montgomery limbs of the right field
+    A = cozk.Vec.from_numpy(ctx, cozk.fr_to_mont_limbs(a, mod))
+    B = cozk.Vec.from_numpy(ctx, cozk.fr_to_mont_limbs(b, mod))
+    for op, f in ((cozk.OP_ADD, lambda x, y: (x + y) % mod), (cozk.OP_SUB, lambda x, y: (x - y) % mod),
+                  (cozk.OP_MUL, lambda x, y: x * y % mod)):
+        got = cozk.mont_limbs_to_int(A.binop(op, B, base_field).to_numpy(), mod)
+        assert got == [f(x, y) for x, y in zip(a, b)]
+
+
+def test_fill_random_matches_oracle_stream(cozk, ctx):
+    v = cozk.Vec.random(ctx, 300, seed=99).to_ints()
+    assert v == O.synthetic_fr(99, 300)
+    v8 = cozk.Vec.random(ctx, 100, seed=5, kind=cozk.SCALAR_U8).to_ints()
+    assert v8 == O.synthetic_small(5, 100, 8)
+    flags = cozk.Vec.random(ctx, 100, seed=6, kind=cozk.SCALAR_U8, max_bits=1).to_ints()
+    assert flags == O.synthetic_small(6, 100, 1) and set(flags) <= {0, 1}
+
+
+def _bases(rng, n):
+    return [O.g1_mul(O.G1_GEN, rng.field()) for _ in range(n)]
+
+
+@pytest.mark.parametrize("precompute", [True, False])
+@pytest.mark.parametrize("n", [1, 2, 3, 17, 256, 1024])
+def test_msm_matches_oracle(cozk, ctx, n, precompute):
+    rng = O.SplitMix64(1000 + n)
+    pts = _bases(rng, n)
+    sc = _rand_fr(rng, n)
+    # edge scalars from SURVEY 8c: zero, one, r-1, small
+    for i, e in enumerate([0, 1, O.R - 1, 7, 65535, 65536, 32768, 32769][:n]):
+        sc[i] = e
+    B = cozk.Bases.upload(ctx, pts, precompute=precompute)
+    got = B.msm(cozk.Vec.from_ints(ctx, sc))
+    assert got == O.msm_naive(pts, sc)
+    # host-scalar form of the seam
+    assert B.msm_host(cozk.fr_to_mont_limbs(sc)) == got
+
+
+def test_msm_infinity_repeats_and_cancellation(cozk, ctx):
+    rng = O.SplitMix64(77)
+    g = O.g1_mul(O.G1_GEN, 5)
+    pts = [g, g, O.g1_neg(g), None, g, O.g1_mul(O.G1_GEN, 9)] + [g] * 200
+    sc = [3, 3, 6, 12345, O.R - 1, 0] + [1] * 200
+    B = cozk.Bases.upload(ctx, pts, precompute=True)
+    assert B.msm(cozk.Vec.from_ints(ctx, sc)) == O.msm_naive(pts, sc)
+    # everything cancels -> infinity
+    pts2 = [g, O.g1_neg(g)]
+    assert cozk.Bases.upload(ctx, pts2, precompute=False).msm(cozk.Vec.from_ints(ctx, [5, 5])) is None
+    # all-zero scalars -> infinity
+    assert B.msm(cozk.Vec.from_ints(ctx, [0] * len(pts))) is None
+
+
+@pytest.mark.parametrize("kind,bits", [("U8", 8), ("U16", 16), ("U32", 32), ("U64", 64), ("U8", 1)])
+def test_msm_small_scalar_kinds(cozk, ctx, kind, bits):
+    n = 700
+    rng = O.SplitMix64(4242)
+    pts = _bases(rng, 64) * 11  # repeated points are legal SRS input
+    pts = pts[:n]
+    k = getattr(cozk, "SCALAR_" + kind)
+    v = cozk.Vec.random(ctx, n, seed=31 + bits, kind=k, max_bits=bits if bits in (1,) else 0)
+    sc = v.to_ints()
+    B = cozk.Bases.upload(ctx, pts, precompute=True)
+    assert B.msm(v) == O.msm_naive(pts, sc)
+
+
+def test_msm_i64(cozk, ctx):
+    rng = O.SplitMix64(5)
+    pts = _bases(rng, 50)
+    vals = [(-1) ** i * (rng.next() >> (i % 40)) for i in range(50)]
+    vals[0] = -(1 << 63)
+    vals[1] = (1 << 63) - 1
+    v = cozk.Vec.from_ints(ctx, vals, kind=cozk.SCALAR_I64)
+    B = cozk.Bases.upload(ctx, pts, precompute=True)
+    assert B.msm(v) == O.msm_naive(pts, [x % O.R for x in vals])
+
+
+def test_batch_msm_mixed_kinds_and_slice(cozk, ctx):
+    n = 512
+    rng = O.SplitMix64(8)
+    pts = _bases(rng, 40) * 13
+    pts = pts[:n + 10]
+    B = cozk.Bases.upload(ctx, pts, precompute=True)
+    vecs = [cozk.Vec.random(ctx, n, seed=1), cozk.Vec.random(ctx, n, seed=2, kind=cozk.SCALAR_U16),
+            cozk.Vec.random(ctx, n, seed=3, kind=cozk.SCALAR_U8, max_bits=1), cozk.Vec.random(ctx, n, seed=4)]
+    got = B.batch_msm(vecs, offset=10)
+    for g, v in zip(got, vecs):
+        assert g == O.msm_naive(pts[10:10 + n], v.to_ints())
+
+
+def test_bases_from_scalars_and_pair_sums(cozk, ctx):
+    s = O.synthetic_fr(3, 64)
+    S = cozk.Vec.from_ints(ctx, s)
+    B = cozk.Bases.from_scalars(ctx, S, precompute=False)
+    pts = B.download()
+    assert pts == [O.g1_mul(O.G1_GEN, x) for x in s]
+    ps = B.pair_sums(precompute=False).download()
+    assert ps == [O.g1_add(pts[2 * i], pts[2 * i + 1]) for i in range(32)]
+
+
+def test_msm_linearity_large(cozk, ctx):
+    """size-independent property at 2^16: MSM(a) + MSM(b) == MSM(a+b) (the identity that
+    pst13.rs:498-546 `test_combine_commitments` checks), bases generated on device."""
+    n = 1 << 16
+    B = cozk.Bases.from_scalars(ctx, cozk.Vec.random(ctx, n, seed=123), precompute=True)
+    a = cozk.Vec.random(ctx, n, seed=1)
+    b = cozk.Vec.random(ctx, n, seed=2)
+    c = a.binop(cozk.OP_ADD, b)
+    pa, pb, pc = B.batch_msm([a, b, c])
+    assert ctx.g1_sum([pa, pb]) == pc
+    assert O.g1_is_on_curve(pc) and pc is not None
