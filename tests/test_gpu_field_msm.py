@@ -89,7 +89,7 @@ def test_msm_small_scalar_kinds(cozk, ctx, kind, bits):
 def test_msm_i64(cozk, ctx):
     rng = O.SplitMix64(5)
     pts = _bases(rng, 50)
-    vals = [(-1) ** i * (rng.next() >> (i % 40)) for i in range(50)]
+    vals = [(-1) ** i * (rng.next() >> (1 + i % 40)) for i in range(50)]
     vals[0] = -(1 << 63)
     vals[1] = (1 << 63) - 1
     v = cozk.Vec.from_ints(ctx, vals, kind=cozk.SCALAR_I64)
@@ -100,7 +100,7 @@ def test_msm_i64(cozk, ctx):
 def test_batch_msm_mixed_kinds_and_slice(cozk, ctx):
     n = 512
     rng = O.SplitMix64(8)
-    pts = _bases(rng, 40) * 13
+    pts = _bases(rng, 40) * 14
     pts = pts[:n + 10]
     B = cozk.Bases.upload(ctx, pts, precompute=True)
     vecs = [cozk.Vec.random(ctx, n, seed=1), cozk.Vec.random(ctx, n, seed=2, kind=cozk.SCALAR_U16),
