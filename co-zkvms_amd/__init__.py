@@ -7,3 +7,5 @@ from ._lib import (CozkError, SCALAR_FR, SCALAR_U8, SCALAR_U16, SCALAR_U32, SCAL
                    LOW_TO_HIGH, HIGH_TO_LOW, MODE_PLAIN, MODE_REP3, OP_ADD, OP_SUB, OP_MUL)
 from .engine import (Context, Vec, Bases, FR_MOD, FQ_MOD, fr_to_mont_limbs, mont_limbs_to_int,
                      point_to_abi, point_from_abi)
+from .poly import (Rep3DensePolynomial, Rep3DenseInterleavedPolynomial, SplitEqPolynomial, eq_evals,
+                   open_quadratic_evals, pst_fold)

@@ -74,6 +74,36 @@ SIGNATURES = {
     "cozk_batch_msm_vec": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
     "cozk_g1_sum": (_i, [_vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_i)]),
     "cozk_g1_mul": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_i)]),
+    "cozk_poly_create": (_i, [_vp, _i, _vp, _vp, _pp]),
+    "cozk_poly_chunk": (_i, [_vp, _vp, _sz, _sz, _pp]),
+    "cozk_poly_free": (_i, [_vp]),
+    "cozk_poly_len": (_sz, [_vp]),
+    "cozk_poly_mode": (_i, [_vp]),
+    "cozk_poly_download": (_i, [_vp, _vp, _vp, _vp]),
+    "cozk_poly_share_view": (_i, [_vp, _vp, _i, _pp]),
+    "cozk_poly_bind": (_i, [_vp, _vp, _vp, _i]),
+    "cozk_poly_get_coeff": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "cozk_eq_evals": (_i, [_vp, _vp, _i, _pp]),
+    "cozk_poly_batch_evaluate_at_chi": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "cozk_poly_dot_product_with_public": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cozk_poly_linear_combination": (_i, [_vp, _vp, _vp, _sz, _i, _i, _pp]),
+    "cozk_open_quadratic_evals": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cozk_pst_fold": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cozk_layer_create": (_i, [_vp, _i, _vp, _vp, _i, _pp]),
+    "cozk_layer_free": (_i, [_vp]),
+    "cozk_layer_len": (_sz, [_vp]),
+    "cozk_layer_download": (_i, [_vp, _vp, _vp, _vp]),
+    "cozk_layer_clone": (_i, [_vp, _vp, _pp]),
+    "cozk_layer_bind": (_i, [_vp, _vp, _vp]),
+    "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cozk_layer_final_claims": (_i, [_vp, _vp, _vp]),
+    "cozk_layer_output_local": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _pp]),
+    "cozk_rep3_mul_vec_local": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _u64, _u64, _u64, _pp]),
+    "cozk_layer_claimed_outputs": (_i, [_vp, _vp, _vp]),
+    "cozk_spliteq_new": (_i, [_vp, _vp, _i, _pp]),
+    "cozk_spliteq_free": (_i, [_vp]),
+    "cozk_spliteq_lens": (_i, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
+    "cozk_spliteq_bind": (_i, [_vp, _vp, _vp]),
     "cozk_prof_enable": (_i, [_vp, _i]),
     "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "cozk_bench_montmul": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(ctypes.c_double)]),

@@ -1,0 +1,974 @@
+// Polynomial seam: device-resident multilinear polynomials over shares.
+//
+//   cozk_poly     <-> Rep3DensePolynomial (co-jolt/src/poly/dense_mlpoly.rs:23-32) / plain DensePolynomial
+//   cozk_layer    <-> Rep3DenseInterleavedPolynomial (co-jolt/src/poly/dense_interleaved_poly.rs:35-48)
+//   cozk_spliteq  <-> SplitEqPolynomial (jolt-core; used dense_interleaved_poly.rs:218-303)
+//
+// All kernels are streaming kernels on 32-byte Montgomery elements (16-byte vector loads per lane);
+// round results (3-4 field elements) are reduced in-kernel (wave shuffle tree + LDS), finished by a
+// one-block kernel, and returned through pinned host memory.
+#include "poly.cuh"
+
+static constexpr int PT = 256;      // threads per block
+static constexpr int MAXBLK = 2048; // grid cap for reducing kernels (>= 8 blocks per CU)
+
+struct cozk_poly {
+    cozk_ctx* ctx;
+    int mode;            // 1 plain, 2 rep3
+    fe* a0; fe* b0;      // unbound coefficients (`coeffs`, immutable; possibly a borrowed chunk view)
+    bool own0;
+    fe* buf[2][2];       // ping-pong bound buffers [which][component]
+    size_t cap[2];
+    int cur;             // -1: unbound, else index of the live bound buffer
+    size_t len;
+    size_t orig_len;
+};
+
+struct cozk_layer {
+    cozk_ctx* ctx;
+    int mode;
+    fe* buf[2][2];       // ping-pong [which][component]
+    size_t cap[2];
+    int cur;
+    size_t len;
+};
+
+struct cozk_spliteq {
+    cozk_ctx* ctx;
+    fe* E1[2]; fe* E2[2];   // ping-pong
+    int c1, c2;
+    size_t E1_len, E2_len, E1_cap, E2_cap;
+    int num_vars;
+};
+
+static inline unsigned grid_for(size_t n) { return (unsigned)((n + PT - 1) / PT); }
+static inline unsigned grid_capped(size_t n) {
+    size_t g = (n + PT - 1) / PT;
+    return (unsigned)(g > MAXBLK ? MAXBLK : (g ? g : 1));
+}
+
+static const fe* poly_a(const cozk_poly* p) { return p->cur < 0 ? p->a0 : p->buf[p->cur][0]; }
+static const fe* poly_b(const cozk_poly* p) { return p->cur < 0 ? p->b0 : p->buf[p->cur][1]; }
+
+// ------------------------------------------------------------------ kernels: dense polynomial
+// bind: out[i] = lo + r (hi - lo); LowToHigh pairs (2i, 2i+1), HighToLow pairs (i, i + n)
+// (dense_mlpoly.rs:310-378).  Algorithmic traffic: read n shares, write n/2 = 96 n bytes (REP3).
+template <int NC, int ORDER>
+__global__ void __launch_bounds__(PT) k_poly_bind(const fe* __restrict__ ia, const fe* __restrict__ ib, fe* oa, fe* ob,
+                                               size_t n_out, fe r) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n_out) return;
+    size_t lo_i = ORDER == COZK_LOW_TO_HIGH ? 2 * i : i;
+    size_t hi_i = ORDER == COZK_LOW_TO_HIGH ? 2 * i + 1 : i + n_out;
+    Sh<NC> lo = sh_load<NC>(ia, ib, lo_i), hi = sh_load<NC>(ia, ib, hi_i);
+    sh_store<NC>(oa, ob, i, sh_lerp<NC>(lo, hi, r));
+}
+
+// partial[blockIdx.y * gridDim.x + blockIdx.x] = sum over this block's stride of (a+b) * chi
+// (evaluate_at_chi, dense_mlpoly.rs:160-181; TWO_INV folded in by the finishing kernel)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_poly_eval_chi(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
+                                                   const size_t* __restrict__ lens, const fe* __restrict__ chi,
+                                                   fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    const fe* a = pa[blockIdx.y];
+    const fe* b = NC == 2 ? pb[blockIdx.y] : nullptr;
+    size_t n = lens[blockIdx.y];
+    fe acc = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < n; i += (size_t)gridDim.x * PT) {
+        Sh<NC> s = sh_load<NC>(a, b, i);
+        acc = Fr::add(acc, Fr::mul(sh_ab_sum<NC>(s), fe_load(chi + i)));
+    }
+    acc = fr_block_sum(acc, sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
+}
+
+// out[y] = scale * sum_x partial[y * nper + x]
+__global__ void __launch_bounds__(PT) k_finish_sums(const fe* __restrict__ partial, unsigned nper, fe scale, int apply_scale,
+                                                 fe* __restrict__ out) {
+    __shared__ fe sh4[4];
+    fe acc = Fr::zero();
+    for (unsigned x = threadIdx.x; x < nper; x += PT) acc = Fr::add(acc, fe_load(partial + (size_t)blockIdx.x * nper + x));
+    acc = fr_block_sum(acc, sh4);
+    if (threadIdx.x == 0) fe_store(out + blockIdx.x, apply_scale ? Fr::mul(acc, scale) : acc);
+}
+
+// per-component dot product with a public vector (dot_product_with_public, dense_mlpoly.rs:228-234)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_poly_dot_public(const fe* __restrict__ a, const fe* __restrict__ b,
+                                                     const fe* __restrict__ pub, size_t n, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    fe acc[NC];
+    for (int k = 0; k < NC; k++) acc[k] = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < n; i += (size_t)gridDim.x * PT) {
+        Sh<NC> s = sh_load<NC>(a, b, i);
+        fe p = fe_load(pub + i);
+        for (int k = 0; k < NC; k++) acc[k] = Fr::add(acc[k], Fr::mul(s.c[k], p));
+    }
+    for (int k = 0; k < NC; k++) {
+        fe v = fr_block_sum(acc[k], sh4);
+        if (threadIdx.x == 0) fe_store(partial + (size_t)k * gridDim.x + blockIdx.x, v);
+    }
+}
+
+// out[i] = sum_k coeff[k] * poly_k[i] (i < len_k)   (linear_combination, dense_mlpoly.rs:195-226;
+// public polynomials enter through their trivial share, multilinear_polynomial.rs:196-296)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_poly_lincomb(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
+                                                  const size_t* __restrict__ lens, const fe* __restrict__ coeffs, int k,
+                                                  fe* oa, fe* ob, size_t n) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    Sh<NC> acc;
+    for (int c = 0; c < NC; c++) acc.c[c] = Fr::zero();
+    for (int j = 0; j < k; j++) {
+        if (i < lens[j]) {
+            fe cf = fe_load(coeffs + j);
+            if (pa[j]) acc.c[0] = Fr::add(acc.c[0], Fr::mul(fe_load(pa[j] + i), cf));
+            if (NC == 2 && pb[j]) acc.c[NC - 1] = Fr::add(acc.c[NC - 1], Fr::mul(fe_load(pb[j] + i), cf));
+        }
+    }
+    sh_store<NC>(oa, ob, i, acc);
+}
+
+// quadratic opening-reduction round (compute_quadratic, opening_proof.rs:374-414): per opening
+// eval_0 = sum_i poly[i]*eq[i], eval_2 = sum_i (2 poly[i+h] - poly[i]) * (2 eq[i+h] - eq[i]);
+// partial[(2*y + e) * gridDim.x + x]; the (a+b)*TWO_INV conversion is folded into the finisher.
+template <int NC>
+__global__ void __launch_bounds__(PT) k_open_quadratic(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
+                                                    const fe* const* __restrict__ peq, const size_t* __restrict__ halves,
+                                                    fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    const fe* a = pa[blockIdx.y];
+    const fe* b = NC == 2 ? pb[blockIdx.y] : nullptr;
+    const fe* eq = peq[blockIdx.y];
+    size_t h = halves[blockIdx.y];
+    fe e0 = Fr::zero(), e2 = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < h; i += (size_t)gridDim.x * PT) {
+        fe q0 = fe_load(eq + i), q1 = fe_load(eq + i + h);
+        fe p0 = sh_ab_sum<NC>(sh_load<NC>(a, b, i)), p1 = sh_ab_sum<NC>(sh_load<NC>(a, b, i + h));
+        e0 = Fr::add(e0, Fr::mul(p0, q0));
+        fe pb2 = Fr::sub(Fr::dbl(p1), p0), qb2 = Fr::sub(Fr::dbl(q1), q0);
+        e2 = Fr::add(e2, Fr::mul(pb2, qb2));
+    }
+    e0 = fr_block_sum(e0, sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)(2 * blockIdx.y) * gridDim.x + blockIdx.x, e0);
+    e2 = fr_block_sum(e2, sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)(2 * blockIdx.y + 1) * gridDim.x + blockIdx.x, e2);
+}
+
+// PST13 `open` fold (pst13.rs:445-459): q[b] = r[2b+1] - r[2b]; r'[b] = r[2b](1-p) + r[2b+1] p
+__global__ void __launch_bounds__(PT) k_pst_fold(const fe* __restrict__ r, fe* __restrict__ q, fe* __restrict__ rn, size_t half, fe p) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= half) return;
+    fe lo = fe_load(r + 2 * i), hi = fe_load(r + 2 * i + 1);
+    fe d = Fr::sub(hi, lo);
+    fe_store(q + i, d);
+    fe_store(rn + i, Fr::add(lo, Fr::mul(d, p)));
+}
+
+// ------------------------------------------------------------------ kernels: interleaved GKR layer
+// bind 4 -> 2 with a zero-padded ragged tail (dense_interleaved_poly.rs:155-195)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_layer_bind(const fe* __restrict__ ia, const fe* __restrict__ ib, fe* oa, fe* ob,
+                                                size_t len, fe r) {
+    size_t c = (size_t)blockIdx.x * PT + threadIdx.x;
+    size_t nch = (len + 3) / 4;
+    if (c >= nch) return;
+    Sh<NC> u0 = sh_load_or_zero<NC>(ia, ib, 4 * c, len), u1 = sh_load_or_zero<NC>(ia, ib, 4 * c + 1, len);
+    Sh<NC> u2 = sh_load_or_zero<NC>(ia, ib, 4 * c + 2, len), u3 = sh_load_or_zero<NC>(ia, ib, 4 * c + 3, len);
+    sh_store<NC>(oa, ob, 2 * c, sh_lerp<NC>(u0, u2, r));
+    sh_store<NC>(oa, ob, 2 * c + 1, sh_lerp<NC>(u1, u3, r));
+}
+
+// eq evaluations at 0, 2, 3 of the linear factor through (e0, e1)
+static __device__ __forceinline__ void eq3(const fe& e0, const fe& e1, fe out[3]) {
+    fe m = Fr::sub(e1, e0);
+    out[0] = e0;
+    out[1] = Fr::add(e1, m);
+    out[2] = Fr::add(out[1], m);
+}
+
+// cubic round evaluations g(0), g(2), g(3) of sum eq * L * R  (compute_cubic,
+// dense_interleaved_poly.rs:210-356).  NESTED = 0: E1 fully bound, eq pairs come from E2 (:218-268);
+// NESTED = 1: Dao-Thaler split, chunk k belongs to x2 = k / (E1_len/2), x1 = k % (E1_len/2) (:269-356).
+template <int NC, int NESTED>
+__global__ void __launch_bounds__(PT) k_layer_cubic(const fe* __restrict__ a, const fe* __restrict__ b, size_t len,
+                                                 const fe* __restrict__ E1, size_t E1_half, const fe* __restrict__ E2,
+                                                 size_t E2_len, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    size_t nch = (len + 3) / 4;
+    size_t limit = NESTED ? E1_half * E2_len : E2_len / 2;
+    if (nch > limit) nch = limit;  // zip() stops at the shorter side
+    fe s0 = Fr::zero(), s2 = Fr::zero(), s3 = Fr::zero();
+    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch; c += (size_t)gridDim.x * PT) {
+        fe e[3];
+        fe scale;
+        if (NESTED) {
+            size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+            eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
+            scale = fe_load(E2 + x2);
+        } else {
+            eq3(fe_load(E2 + 2 * c), fe_load(E2 + 2 * c + 1), e);
+        }
+        Sh<NC> l0 = sh_load_or_zero<NC>(a, b, 4 * c, len), r0 = sh_load_or_zero<NC>(a, b, 4 * c + 1, len);
+        Sh<NC> l1 = sh_load_or_zero<NC>(a, b, 4 * c + 2, len), r1 = sh_load_or_zero<NC>(a, b, 4 * c + 3, len);
+        Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
+        Sh<NC> l2 = sh_add<NC>(l1, ml), r2 = sh_add<NC>(r1, mr);
+        Sh<NC> l3 = sh_add<NC>(l2, ml), r3 = sh_add<NC>(r2, mr);
+        fe t0 = Fr::mul(sh_local_mul<NC>(l0, r0), e[0]);
+        fe t2 = Fr::mul(sh_local_mul<NC>(l2, r2), e[1]);
+        fe t3 = Fr::mul(sh_local_mul<NC>(l3, r3), e[2]);
+        if (NESTED) {
+            t0 = Fr::mul(t0, scale);
+            t2 = Fr::mul(t2, scale);
+            t3 = Fr::mul(t3, scale);
+        }
+        s0 = Fr::add(s0, t0);
+        s2 = Fr::add(s2, t2);
+        s3 = Fr::add(s3, t3);
+    }
+    s0 = fr_block_sum(s0, sh4);
+    if (threadIdx.x == 0) fe_store(partial + blockIdx.x, s0);
+    s2 = fr_block_sum(s2, sh4);
+    if (threadIdx.x == 0) fe_store(partial + gridDim.x + blockIdx.x, s2);
+    s3 = fr_block_sum(s3, sh4);
+    if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, s3);
+}
+
+static __device__ __forceinline__ uint64_t sm_next(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// PRF(seed, j): canonical value < r from the stream seeded with seed + j * 0xD1342543DE82EF95,
+// returned in Montgomery form (same generator as cozk_vec_fill_random)
+static __device__ __forceinline__ fe prf_fr(uint64_t seed, uint64_t j) {
+    uint64_t s = seed + j * 0xD1342543DE82EF95ull;
+    fe v;
+    for (;;) {
+        uint64_t w0 = sm_next(s), w1 = sm_next(s), w2 = sm_next(s), w3 = sm_next(s) & ((1ull << 62) - 1ull);
+        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
+        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
+        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
+        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
+        if (!Fr::geq_mod(v)) break;
+    }
+    return Fr::to_mont(v);
+}
+
+// out[j] = L[j] x R[j] (+ mask_j): local half of `mul_vec` (layer_output,
+// dense_interleaved_poly.rs:122-141; local product ops.rs:71-78; zero-sharing mask
+// mask_j = PRF(seed_self, ctr+j) - PRF(seed_prev, ctr+j))
+template <int NC>
+__global__ void __launch_bounds__(PT) k_layer_output(const fe* __restrict__ a, const fe* __restrict__ b, size_t len,
+                                                  fe* __restrict__ out, size_t n_out, int masked, uint64_t seed_self,
+                                                  uint64_t seed_prev, uint64_t ctr) {
+    size_t j = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (j >= n_out) return;
+    Sh<NC> l = sh_load_or_zero<NC>(a, b, 2 * j, len), r = sh_load_or_zero<NC>(a, b, 2 * j + 1, len);
+    fe v = sh_local_mul<NC>(l, r);
+    if (masked) v = Fr::add(v, Fr::sub(prf_fr(seed_self, ctr + j), prf_fr(seed_prev, ctr + j)));
+    fe_store(out + j, v);
+}
+
+// element-wise Rep3 mul_vec local part on two share vectors (rep3::arithmetic::mul_vec)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_mul_vec_local(const fe* __restrict__ xa, const fe* __restrict__ xb,
+                                                   const fe* __restrict__ ya, const fe* __restrict__ yb, size_t n,
+                                                   fe* __restrict__ out, int masked, uint64_t seed_self, uint64_t seed_prev,
+                                                   uint64_t ctr) {
+    size_t j = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (j >= n) return;
+    fe v = sh_local_mul<NC>(sh_load<NC>(xa, xb, j), sh_load<NC>(ya, yb, j));
+    if (masked) v = Fr::add(v, Fr::sub(prf_fr(seed_self, ctr + j), prf_fr(seed_prev, ctr + j)));
+    fe_store(out + j, v);
+}
+
+// ------------------------------------------------------------------ kernels: split-eq tables
+__global__ void __launch_bounds__(PT) k_fold_pairs(const fe* __restrict__ in, fe* __restrict__ out, size_t n_out, fe r) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n_out) return;
+    fe lo = fe_load(in + 2 * i), hi = fe_load(in + 2 * i + 1);
+    fe_store(out + i, Fr::add(lo, Fr::mul(Fr::sub(hi, lo), r)));
+}
+__global__ void __launch_bounds__(PT) k_fold_halves(fe* __restrict__ v, size_t n_out, fe r) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n_out) return;
+    fe lo = fe_load(v + i), hi = fe_load(v + i + n_out);
+    fe_store(v + i, Fr::add(lo, Fr::mul(Fr::sub(hi, lo), r)));
+}
+__global__ void __launch_bounds__(PT) k_scale_by_first(fe* __restrict__ v, size_t n, const fe* __restrict__ s) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    fe_store(v + i, Fr::mul(fe_load(v + i), fe_load(s)));
+}
+// EqPolynomial::evals(r) on device, big-endian (r[0] <-> MSB): level j doubles the table
+__global__ void __launch_bounds__(PT) k_eq_expand(const fe* __restrict__ in, fe* __restrict__ out, size_t n_in, fe rj) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n_in) return;
+    fe e = fe_load(in + i);
+    fe hi = Fr::mul(e, rj);
+    fe_store(out + 2 * i, Fr::sub(e, hi));
+    fe_store(out + 2 * i + 1, hi);
+}
+
+// ------------------------------------------------------------------ host helpers
+static fe* dev_alloc_fe(size_t n) {
+    void* p = nullptr;
+    HIP_TRY(hipMalloc(&p, (n ? n : 1) * sizeof(fe)));
+    return (fe*)p;
+}
+
+// copy k small results from device scratch to host (sync)
+static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
+    fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
+    HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < k; i++) h[i] = pin[i];
+}
+
+// build an eq table on device: out (len 2^nv) from point r (host), big-endian
+static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp) {
+    fe one = Fr::one();
+    fe* cur = (nv % 2 == 0) ? out : tmp;  // ping-pong so that the last level lands in `out`
+    fe* nxt = (nv % 2 == 0) ? tmp : out;
+    HIP_TRY(hipMemcpyAsync(cur, &one, sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `one` lives on the stack
+    size_t n = 1;
+    for (int j = 0; j < nv; j++) {
+        k_eq_expand<<<grid_for(n), PT, 0, ctx->stream>>>(cur, nxt, n, r[j]);
+        std::swap(cur, nxt);
+        n *= 2;
+    }
+    HIP_TRY(hipGetLastError());
+}
+
+// unique polynomial through (i, evals[i]), i = 0..n-1 (UniPoly::from_evals), n in {3, 4}
+static void unipoly_from_evals(const fe* ev, int n, fe* coeffs) {
+    // Lagrange on the fixed nodes 0..n-1 with small-integer inverses
+    fe inv2 = fr_two_inv();
+    if (n == 3) {
+        // c0 = e0; c2 = (e2 - 2 e1 + e0)/2; c1 = e1 - e0 - c2
+        fe c2 = Fr::mul(Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]), inv2);
+        coeffs[0] = ev[0];
+        coeffs[2] = c2;
+        coeffs[1] = Fr::sub(Fr::sub(ev[1], ev[0]), c2);
+        return;
+    }
+    // n == 4: finite differences: d1 = e1-e0, d2 = e2-2e1+e0, d3 = e3-3e2+3e1-e0
+    fe inv6 = Fr::inv(Fr::from_u64(6));
+    fe d1 = Fr::sub(ev[1], ev[0]);
+    fe d2 = Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]);
+    fe three_e2 = Fr::add(Fr::dbl(ev[2]), ev[2]), three_e1 = Fr::add(Fr::dbl(ev[1]), ev[1]);
+    fe d3 = Fr::sub(Fr::add(Fr::sub(ev[3], three_e2), three_e1), ev[0]);
+    // p(x) = e0 + d1 x + d2 x(x-1)/2 + d3 x(x-1)(x-2)/6
+    fe a3 = Fr::mul(d3, inv6);
+    fe h2 = Fr::mul(d2, inv2);
+    // x(x-1)/2 -> h2 (x^2 - x); x(x-1)(x-2)/6 -> a3 (x^3 - 3x^2 + 2x)
+    fe three_a3 = Fr::add(Fr::dbl(a3), a3);
+    coeffs[0] = ev[0];
+    coeffs[1] = Fr::add(Fr::sub(d1, h2), Fr::dbl(a3));
+    coeffs[2] = Fr::sub(h2, three_a3);
+    coeffs[3] = a3;
+}
+
+// ------------------------------------------------------------------ C ABI: dense polynomial
+extern "C" {
+
+int cozk_poly_create(cozk_ctx* ctx, int mode, const cozk_vec* a, const cozk_vec* b, cozk_poly** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out && a && a->kind == COZK_SCALAR_FR && (mode == COZK_MODE_PLAIN || mode == COZK_MODE_REP3),
+                     "poly_create: bad argument");
+        COZK_REQUIRE(mode == COZK_MODE_PLAIN || (b && b->kind == COZK_SCALAR_FR && b->n == a->n), "poly_create: share b missing");
+        cozk_poly* p = new cozk_poly();
+        p->ctx = ctx;
+        p->mode = mode;
+        p->len = p->orig_len = a->n;
+        p->cur = -1;
+        p->own0 = true;
+        p->a0 = dev_alloc_fe(a->n);
+        p->b0 = nullptr;
+        HIP_TRY(hipMemcpyAsync(p->a0, a->d, a->n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+        if (mode == COZK_MODE_REP3) {
+            p->b0 = dev_alloc_fe(a->n);
+            HIP_TRY(hipMemcpyAsync(p->b0, b->d, a->n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        *out = p;
+    });
+}
+
+// zero-copy chunk view over the high variables (`split_poly`, dense_mlpoly.rs:275-301)
+int cozk_poly_chunk(cozk_ctx* ctx, const cozk_poly* src, size_t offset, size_t len, cozk_poly** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && src && out && src->cur < 0 && offset + len <= src->orig_len, "poly_chunk: bad argument (source must be unbound)");
+        cozk_poly* p = new cozk_poly();
+        p->ctx = ctx;
+        p->mode = src->mode;
+        p->len = p->orig_len = len;
+        p->cur = -1;
+        p->own0 = false;
+        p->a0 = src->a0 + offset;
+        p->b0 = src->b0 ? src->b0 + offset : nullptr;
+        *out = p;
+    });
+}
+
+int cozk_poly_free(cozk_poly* p) {
+    if (!p) return COZK_OK;
+    if (p->own0) {
+        if (p->a0) (void)hipFree(p->a0);
+        if (p->b0) (void)hipFree(p->b0);
+    }
+    for (int w = 0; w < 2; w++)
+        for (int c = 0; c < 2; c++)
+            if (p->buf[w][c]) (void)hipFree(p->buf[w][c]);
+    delete p;
+    return COZK_OK;
+}
+
+size_t cozk_poly_len(const cozk_poly* p) { return p ? p->len : 0; }
+int cozk_poly_mode(const cozk_poly* p) { return p ? p->mode : 0; }
+
+// current coefficients -> host (a: len x 4 u64; b likewise or NULL)
+int cozk_poly_download(cozk_ctx* ctx, const cozk_poly* p, uint64_t* a, uint64_t* b) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && p && a, "poly_download: bad argument");
+        HIP_TRY(hipMemcpyAsync(a, poly_a(p), p->len * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        if (p->mode == COZK_MODE_REP3 && b)
+            HIP_TRY(hipMemcpyAsync(b, poly_b(p), p->len * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// `copy_share_a` (dense_mlpoly.rs:103-110) as a zero-copy view of the current coefficients
+int cozk_poly_share_view(cozk_ctx* ctx, const cozk_poly* p, int component, cozk_vec** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && p && out && (component == 0 || (component == 1 && p->mode == COZK_MODE_REP3)), "poly_share_view: bad argument");
+        const fe* d = component == 0 ? poly_a(p) : poly_b(p);
+        *out = new cozk_vec{ctx, p->len, COZK_SCALAR_FR, (void*)d, p->len * sizeof(fe), false};
+    });
+}
+
+// PolynomialBinding::bind / bind_parallel (dense_mlpoly.rs:310-459; the correct `left +` formula
+// is used for every case -- see SURVEY 9 on the reference's bind_parallel quirk)
+int cozk_poly_bind(cozk_ctx* ctx, cozk_poly* p, const uint64_t r[4], int order) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && p && r && p->len >= 2 && (order == COZK_LOW_TO_HIGH || order == COZK_HIGH_TO_LOW), "poly_bind: bad argument");
+        size_t n = p->len / 2;
+        fe rr = fe_from_u64x4(r);
+        const fe* ia = poly_a(p);
+        const fe* ib = poly_b(p);
+        int dst;
+        if (p->cur >= 0 && order == COZK_HIGH_TO_LOW) {
+            dst = p->cur;  // in place: lane i reads (i, i+n) and writes i
+        } else {
+            dst = p->cur < 0 ? 0 : 1 - p->cur;
+            if (p->cap[dst] < n) {
+                for (int c = 0; c < 2; c++) {
+                    if (p->buf[dst][c]) HIP_TRY(hipFree(p->buf[dst][c]));
+                    p->buf[dst][c] = nullptr;
+                }
+                p->buf[dst][0] = dev_alloc_fe(n);
+                if (p->mode == COZK_MODE_REP3) p->buf[dst][1] = dev_alloc_fe(n);
+                p->cap[dst] = n;
+            }
+        }
+        fe* oa = p->buf[dst][0];
+        fe* ob = p->buf[dst][1];
+        if (p->mode == COZK_MODE_REP3) {
+            if (order == COZK_LOW_TO_HIGH) k_poly_bind<2, COZK_LOW_TO_HIGH><<<grid_for(n), PT, 0, ctx->stream>>>(ia, ib, oa, ob, n, rr);
+            else k_poly_bind<2, COZK_HIGH_TO_LOW><<<grid_for(n), PT, 0, ctx->stream>>>(ia, ib, oa, ob, n, rr);
+        } else {
+            if (order == COZK_LOW_TO_HIGH) k_poly_bind<1, COZK_LOW_TO_HIGH><<<grid_for(n), PT, 0, ctx->stream>>>(ia, ib, oa, ob, n, rr);
+            else k_poly_bind<1, COZK_HIGH_TO_LOW><<<grid_for(n), PT, 0, ctx->stream>>>(ia, ib, oa, ob, n, rr);
+        }
+        HIP_TRY(hipGetLastError());
+        p->cur = dst;
+        p->len = n;
+    });
+}
+
+// get_bound_coeff / final_sumcheck_claim (dense_mlpoly.rs:251-257,461-465)
+int cozk_poly_get_coeff(cozk_ctx* ctx, const cozk_poly* p, size_t index, uint64_t a[4], uint64_t b[4]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && p && a && index < p->len, "poly_get_coeff: bad argument");
+        fe h[2];
+        fetch_fe(ctx, poly_a(p) + index, 1, &h[0]);
+        fe_to_u64x4(h[0], a);
+        if (p->mode == COZK_MODE_REP3 && b) {
+            fetch_fe(ctx, poly_b(p) + index, 1, &h[1]);
+            fe_to_u64x4(h[1], b);
+        }
+    });
+}
+
+// build EqPolynomial::evals(r) on device (big-endian) -> cozk_vec of 2^nv elements
+int cozk_eq_evals(cozk_ctx* ctx, const uint64_t* r, int nv, cozk_vec** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out && nv >= 0 && nv < 40 && (r || nv == 0), "eq_evals: bad argument");
+        size_t n = (size_t)1 << nv;
+        std::vector<fe> rr(nv);
+        for (int j = 0; j < nv; j++) rr[j] = fe_from_u64x4(r + 4 * j);
+        fe* d = dev_alloc_fe(n);
+        ctx->scratch2.reserve(n * sizeof(fe));
+        eq_evals_device(ctx, rr.data(), nv, d, ctx->scratch2.as<fe>());
+        *out = new cozk_vec{ctx, n, COZK_SCALAR_FR, d, n * sizeof(fe), true};
+    });
+}
+
+// Rep3DensePolynomial::batch_evaluate (dense_mlpoly.rs:183-192): out[k] = additive share of poly_k(r)
+// = TWO_INV * sum_i (a_i + b_i) chi_i (REP3) or sum_i a_i chi_i (PLAIN).  chi: FR vec, len >= max len.
+int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys, size_t k, const cozk_vec* chi,
+                                    uint64_t* out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && polys && k > 0 && chi && out && chi->kind == COZK_SCALAR_FR, "batch_evaluate: bad argument");
+        int mode = polys[0]->mode;
+        size_t maxlen = 0;
+        std::vector<const fe*> ha(k), hb(k);
+        std::vector<size_t> hl(k);
+        for (size_t i = 0; i < k; i++) {
+            COZK_REQUIRE(polys[i] && polys[i]->mode == mode, "batch_evaluate: mixed share modes");
+            COZK_REQUIRE(polys[i]->len <= chi->n, "batch_evaluate: chi shorter than polynomial");
+            ha[i] = poly_a(polys[i]);
+            hb[i] = poly_b(polys[i]);
+            hl[i] = polys[i]->len;
+            if (hl[i] > maxlen) maxlen = hl[i];
+        }
+        unsigned gx = grid_capped(maxlen);
+        if (gx > 512) gx = 512;
+        size_t meta = k * (2 * sizeof(void*) + sizeof(size_t));
+        ctx->scratch.reserve(meta + (k * gx + k) * sizeof(fe) + 64);
+        char* base = (char*)ctx->scratch.p;
+        const fe** da = (const fe**)base;
+        const fe** db = da + k;
+        size_t* dl = (size_t*)(db + k);
+        fe* partial = (fe*)(((uintptr_t)(dl + k) + 31) & ~(uintptr_t)31);
+        fe* res = partial + k * gx;
+        HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
+        dim3 grid(gx, (unsigned)k);
+        if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+        else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+        k_finish_sums<<<(unsigned)k, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
+        HIP_TRY(hipGetLastError());
+        std::vector<fe> h(k);
+        fetch_fe(ctx, res, k, h.data());
+        for (size_t i = 0; i < k; i++) fe_to_u64x4(h[i], out + 4 * i);
+    });
+}
+
+// dot_product_with_public (dense_mlpoly.rs:228-234) -> share (a[4], b[4])
+int cozk_poly_dot_product_with_public(cozk_ctx* ctx, const cozk_poly* p, const cozk_vec* pub, uint64_t a[4], uint64_t b[4]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && p && pub && a && pub->kind == COZK_SCALAR_FR && pub->n == p->len, "dot_product: length mismatch (zip_eq)");
+        unsigned gx = grid_capped(p->len);
+        if (gx > 512) gx = 512;
+        ctx->scratch.reserve((2 * gx + 2) * sizeof(fe));
+        fe* partial = ctx->scratch.as<fe>();
+        fe* res = partial + 2 * gx;
+        int nc = p->mode == COZK_MODE_REP3 ? 2 : 1;
+        if (nc == 2) k_poly_dot_public<2><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
+        else k_poly_dot_public<1><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
+        k_finish_sums<<<nc, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        HIP_TRY(hipGetLastError());
+        fe h[2];
+        fetch_fe(ctx, res, nc, h);
+        fe_to_u64x4(h[0], a);
+        if (nc == 2 && b) fe_to_u64x4(h[1], b);
+    });
+}
+
+// Rep3DensePolynomial::linear_combination / Rep3MultilinearPolynomial::linear_combination
+// (dense_mlpoly.rs:195-226; multilinear_polynomial.rs:196-296).  A PLAIN polynomial inside a REP3
+// combination is a public polynomial entering through its trivial share (P0: a = v, P1: b = v,
+// P2: nothing; types.rs:90-96) -- `party_id` selects which.
+int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, const uint64_t* coeffs, size_t k,
+                                 int out_mode, int party_id, cozk_poly** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && polys && coeffs && k > 0 && out && (out_mode == COZK_MODE_PLAIN || out_mode == COZK_MODE_REP3) &&
+                         party_id >= 0 && party_id < 3,
+                     "linear_combination: bad argument");
+        size_t maxlen = 0;
+        std::vector<const fe*> ha(k), hb(k);
+        std::vector<size_t> hl(k);
+        std::vector<fe> hc(k);
+        for (size_t i = 0; i < k; i++) {
+            const cozk_poly* p = polys[i];
+            COZK_REQUIRE(p, "linear_combination: null polynomial");
+            hl[i] = p->len;
+            hc[i] = fe_from_u64x4(coeffs + 4 * i);
+            if (p->len > maxlen) maxlen = p->len;
+            if (p->mode == COZK_MODE_REP3) {
+                COZK_REQUIRE(out_mode == COZK_MODE_REP3, "linear_combination: shared input needs a shared output");
+                ha[i] = poly_a(p);
+                hb[i] = poly_b(p);
+            } else if (out_mode == COZK_MODE_REP3) {
+                // public polynomial: `add_public` puts it on P0's a / P1's b / nowhere on P2
+                // (SharedOrPublic::add_public_assign, co-jolt/src/utils/shared_or_public.rs:150-152)
+                ha[i] = party_id == 0 ? poly_a(p) : nullptr;
+                hb[i] = party_id == 1 ? poly_a(p) : nullptr;
+            } else {
+                ha[i] = poly_a(p);
+                hb[i] = nullptr;
+            }
+        }
+        cozk_poly* o = new cozk_poly();
+        o->ctx = ctx;
+        o->mode = out_mode;
+        o->len = o->orig_len = maxlen;
+        o->cur = -1;
+        o->own0 = true;
+        o->a0 = dev_alloc_fe(maxlen);
+        o->b0 = out_mode == COZK_MODE_REP3 ? dev_alloc_fe(maxlen) : nullptr;
+        size_t meta = k * (2 * sizeof(void*) + sizeof(size_t)) + 64 + k * sizeof(fe);
+        ctx->scratch.reserve(meta + 64);
+        char* base = (char*)ctx->scratch.p;
+        const fe** da = (const fe**)base;
+        const fe** db = da + k;
+        size_t* dl = (size_t*)(db + k);
+        fe* dc = (fe*)(((uintptr_t)(dl + k) + 31) & ~(uintptr_t)31);
+        HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dc, hc.data(), k * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (out_mode == COZK_MODE_REP3) k_poly_lincomb<2><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
+        else k_poly_lincomb<1><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
+        HIP_TRY(hipGetLastError());
+        *out = o;
+    });
+}
+
+// one round of the batched opening-reduction sumcheck for the openings that are "live" this round
+// (compute_quadratic, opening_proof.rs:374-414): out[2*i] = eval_0, out[2*i+1] = eval_2 as additive
+// shares (REP3: TWO_INV * (a+b) already applied; PLAIN: the value).
+int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys, const cozk_poly* const* eqs, size_t k,
+                              uint64_t* out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && polys && eqs && k > 0 && out, "open_quadratic: bad argument");
+        int mode = polys[0]->mode;
+        std::vector<const fe*> ha(k), hb(k), he(k);
+        std::vector<size_t> hh(k);
+        size_t maxh = 0;
+        for (size_t i = 0; i < k; i++) {
+            COZK_REQUIRE(polys[i] && eqs[i] && polys[i]->mode == mode && eqs[i]->mode == COZK_MODE_PLAIN &&
+                             eqs[i]->len == polys[i]->len && polys[i]->len >= 2,
+                         "open_quadratic: polynomial / eq mismatch");
+            ha[i] = poly_a(polys[i]);
+            hb[i] = poly_b(polys[i]);
+            he[i] = poly_a(eqs[i]);
+            hh[i] = polys[i]->len / 2;
+            if (hh[i] > maxh) maxh = hh[i];
+        }
+        unsigned gx = grid_capped(maxh);
+        if (gx > 512) gx = 512;
+        size_t meta = k * (3 * sizeof(void*) + sizeof(size_t));
+        ctx->scratch.reserve(meta + (2 * k * gx + 2 * k) * sizeof(fe) + 64);
+        char* base = (char*)ctx->scratch.p;
+        const fe** da = (const fe**)base;
+        const fe** db = da + k;
+        const fe** de = db + k;
+        size_t* dh = (size_t*)(de + k);
+        fe* partial = (fe*)(((uintptr_t)(dh + k) + 31) & ~(uintptr_t)31);
+        fe* res = partial + 2 * k * gx;
+        HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(de, he.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(dh, hh.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        dim3 grid(gx, (unsigned)k);
+        if (mode == COZK_MODE_REP3) k_open_quadratic<2><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
+        else k_open_quadratic<1><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
+        k_finish_sums<<<(unsigned)(2 * k), PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
+        HIP_TRY(hipGetLastError());
+        std::vector<fe> h(2 * k);
+        fetch_fe(ctx, res, 2 * k, h.data());
+        for (size_t i = 0; i < 2 * k; i++) fe_to_u64x4(h[i], out + 4 * i);
+    });
+}
+
+// PST13 `open` fold step (pst13.rs:445-459): r (len 2h) -> q (len h), r' (len h)
+int cozk_pst_fold(cozk_ctx* ctx, const cozk_vec* r, const uint64_t p[4], cozk_vec* q, cozk_vec* r_next) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && r && p && q && r_next && r->kind == COZK_SCALAR_FR && r->n >= 2 && r->n % 2 == 0 &&
+                         q->n >= r->n / 2 && r_next->n >= r->n / 2,
+                     "pst_fold: bad argument");
+        size_t h = r->n / 2;
+        k_pst_fold<<<grid_for(h), PT, 0, ctx->stream>>>((const fe*)r->d, (fe*)q->d, (fe*)r_next->d, h, fe_from_u64x4(p));
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+// ------------------------------------------------------------------ C ABI: interleaved GKR layer
+int cozk_layer_create(cozk_ctx* ctx, int mode, const cozk_vec* a, const cozk_vec* b, int take_ownership, cozk_layer** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out && a && a->kind == COZK_SCALAR_FR && a->n % 2 == 0 && (mode == COZK_MODE_PLAIN || mode == COZK_MODE_REP3),
+                     "layer_create: bad argument (coeffs.len() % 2 == 0, dense_interleaved_poly.rs:62)");
+        COZK_REQUIRE(mode == COZK_MODE_PLAIN || (b && b->kind == COZK_SCALAR_FR && b->n == a->n), "layer_create: share b missing");
+        cozk_layer* l = new cozk_layer();
+        l->ctx = ctx;
+        l->mode = mode;
+        l->len = a->n;
+        l->cur = 0;
+        l->cap[0] = a->n;
+        if (take_ownership) {
+            COZK_REQUIRE(a->owned && (mode == COZK_MODE_PLAIN || b->owned), "layer_create: cannot take ownership of a view");
+            l->buf[0][0] = (fe*)a->d;
+            const_cast<cozk_vec*>(a)->owned = false;
+            if (mode == COZK_MODE_REP3) {
+                l->buf[0][1] = (fe*)b->d;
+                const_cast<cozk_vec*>(b)->owned = false;
+            }
+        } else {
+            l->buf[0][0] = dev_alloc_fe(a->n);
+            HIP_TRY(hipMemcpyAsync(l->buf[0][0], a->d, a->n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+            if (mode == COZK_MODE_REP3) {
+                l->buf[0][1] = dev_alloc_fe(a->n);
+                HIP_TRY(hipMemcpyAsync(l->buf[0][1], b->d, a->n * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
+        *out = l;
+    });
+}
+
+int cozk_layer_free(cozk_layer* l) {
+    if (!l) return COZK_OK;
+    for (int w = 0; w < 2; w++)
+        for (int c = 0; c < 2; c++)
+            if (l->buf[w][c]) (void)hipFree(l->buf[w][c]);
+    delete l;
+    return COZK_OK;
+}
+
+size_t cozk_layer_len(const cozk_layer* l) { return l ? l->len : 0; }
+
+int cozk_layer_download(cozk_ctx* ctx, const cozk_layer* l, uint64_t* a, uint64_t* b) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && a, "layer_download: bad argument");
+        HIP_TRY(hipMemcpyAsync(a, l->buf[l->cur][0], l->len * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        if (l->mode == COZK_MODE_REP3 && b)
+            HIP_TRY(hipMemcpyAsync(b, l->buf[l->cur][1], l->len * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    });
+}
+
+// deep copy (the GKR prover binds layers destructively; tests and the harness keep the originals)
+int cozk_layer_clone(cozk_ctx* ctx, const cozk_layer* src, cozk_layer** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && src && out, "layer_clone: bad argument");
+        cozk_layer* l = new cozk_layer();
+        l->ctx = ctx;
+        l->mode = src->mode;
+        l->len = src->len;
+        l->cur = 0;
+        l->cap[0] = src->len;
+        for (int c = 0; c < (src->mode == COZK_MODE_REP3 ? 2 : 1); c++) {
+            l->buf[0][c] = dev_alloc_fe(src->len);
+            HIP_TRY(hipMemcpyAsync(l->buf[0][c], src->buf[src->cur][c], src->len * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+        }
+        *out = l;
+    });
+}
+
+// Rep3Bindable::bind (dense_interleaved_poly.rs:155-195)
+int cozk_layer_bind(cozk_ctx* ctx, cozk_layer* l, const uint64_t r[4]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && r && l->len >= 2, "layer_bind: bad argument");
+        size_t nch = (l->len + 3) / 4;
+        size_t nout = 2 * nch;
+        int dst = 1 - l->cur;
+        if (l->cap[dst] < nout) {
+            for (int c = 0; c < 2; c++) {
+                if (l->buf[dst][c]) HIP_TRY(hipFree(l->buf[dst][c]));
+                l->buf[dst][c] = nullptr;
+            }
+            l->buf[dst][0] = dev_alloc_fe(nout);
+            if (l->mode == COZK_MODE_REP3) l->buf[dst][1] = dev_alloc_fe(nout);
+            l->cap[dst] = nout;
+        }
+        fe rr = fe_from_u64x4(r);
+        if (l->mode == COZK_MODE_REP3)
+            k_layer_bind<2><<<grid_for(nch), PT, 0, ctx->stream>>>(l->buf[l->cur][0], l->buf[l->cur][1], l->buf[dst][0], l->buf[dst][1], l->len, rr);
+        else
+            k_layer_bind<1><<<grid_for(nch), PT, 0, ctx->stream>>>(l->buf[l->cur][0], nullptr, l->buf[dst][0], nullptr, l->len, rr);
+        HIP_TRY(hipGetLastError());
+        l->cur = dst;
+        l->len = nout;
+    });
+}
+
+// SplitEqPolynomial::new(w) (jolt-core; m = len/2, E2 = evals(w[..m]), E1 = evals(w[m..]))
+int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && out && nv >= 0 && nv < 60 && (w || nv == 0), "spliteq_new: bad argument");
+        int m = nv / 2;
+        cozk_spliteq* e = new cozk_spliteq();
+        e->ctx = ctx;
+        e->num_vars = nv;
+        e->E2_len = e->E2_cap = (size_t)1 << m;
+        e->E1_len = e->E1_cap = (size_t)1 << (nv - m);
+        for (int k = 0; k < 2; k++) {
+            e->E1[k] = dev_alloc_fe(e->E1_cap);
+            e->E2[k] = dev_alloc_fe(e->E2_cap);
+        }
+        std::vector<fe> rr(nv);
+        for (int j = 0; j < nv; j++) rr[j] = fe_from_u64x4(w + 4 * j);
+        eq_evals_device(ctx, rr.data(), m, e->E2[0], e->E2[1]);
+        eq_evals_device(ctx, rr.data() + m, nv - m, e->E1[0], e->E1[1]);
+        e->c1 = e->c2 = 0;
+        *out = e;
+    });
+}
+
+int cozk_spliteq_free(cozk_spliteq* e) {
+    if (!e) return COZK_OK;
+    for (int k = 0; k < 2; k++) {
+        if (e->E1[k]) (void)hipFree(e->E1[k]);
+        if (e->E2[k]) (void)hipFree(e->E2[k]);
+    }
+    delete e;
+    return COZK_OK;
+}
+
+int cozk_spliteq_lens(const cozk_spliteq* e, size_t* e1_len, size_t* e2_len) {
+    if (!e) return COZK_ERR_INVALID_ARG;
+    if (e1_len) *e1_len = e->E1_len;
+    if (e2_len) *e2_len = e->E2_len;
+    return COZK_OK;
+}
+
+// SplitEqPolynomial::bind(r)
+int cozk_spliteq_bind(cozk_ctx* ctx, cozk_spliteq* e, const uint64_t r[4]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && e && r, "spliteq_bind: bad argument");
+        fe rr = fe_from_u64x4(r);
+        if (e->E1_len == 1) {
+            COZK_REQUIRE(e->E2_len >= 2, "spliteq_bind: polynomial already fully bound");
+            size_t n = e->E2_len / 2;
+            k_fold_pairs<<<grid_for(n), PT, 0, ctx->stream>>>(e->E2[e->c2], e->E2[1 - e->c2], n, rr);
+            e->c2 = 1 - e->c2;
+            e->E2_len = n;
+        } else {
+            size_t n = e->E1_len / 2;
+            k_fold_pairs<<<grid_for(n), PT, 0, ctx->stream>>>(e->E1[e->c1], e->E1[1 - e->c1], n, rr);
+            e->c1 = 1 - e->c1;
+            e->E1_len = n;
+            if (n == 1) k_scale_by_first<<<grid_for(e->E2_len), PT, 0, ctx->stream>>>(e->E2[e->c2], e->E2_len, e->E1[e->c1]);
+        }
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+// Rep3BatchedCubicSumcheckWorker::compute_cubic (dense_interleaved_poly.rs:210-365): returns the 4
+// additive coefficient shares of the round polynomial through evals [g0, claim - g0, g2, g3]
+int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq, const uint64_t prev_claim[4],
+                             uint64_t out_coeffs[16]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && eq && prev_claim && out_coeffs, "compute_cubic: bad argument");
+        size_t nch = (l->len + 3) / 4;
+        unsigned gx = grid_capped(nch);
+        if (gx > 1024) gx = 1024;
+        ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
+        fe* partial = ctx->scratch.as<fe>();
+        fe* res = partial + 3 * (size_t)gx;
+        const fe* a = l->buf[l->cur][0];
+        const fe* b = l->buf[l->cur][1];
+        const fe* E1 = eq->E1[eq->c1];
+        const fe* E2 = eq->E2[eq->c2];
+        bool nested = eq->E1_len != 1;
+        if (l->mode == COZK_MODE_REP3) {
+            if (nested) k_layer_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+            else k_layer_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+        } else {
+            if (nested) k_layer_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+            else k_layer_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+        }
+        k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        HIP_TRY(hipGetLastError());
+        fe s[3];
+        fetch_fe(ctx, res, 3, s);
+        fe ev[4] = {s[0], Fr::sub(fe_from_u64x4(prev_claim), s[0]), s[1], s[2]};
+        fe cf[4];
+        unipoly_from_evals(ev, 4, cf);
+        for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], out_coeffs + 4 * i);
+    });
+}
+
+// final_claims (dense_interleaved_poly.rs:367-372): coeffs[0], coeffs[1]; out = L.a, L.b, R.a, R.b
+int cozk_layer_final_claims(cozk_ctx* ctx, const cozk_layer* l, uint64_t out[16]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && out && l->len == 2, "final_claims: layer must be fully bound (len == 2)");
+        fe h[2];
+        fetch_fe(ctx, l->buf[l->cur][0], 2, h);
+        fe_to_u64x4(h[0], out);
+        fe_to_u64x4(h[1], out + 8);
+        if (l->mode == COZK_MODE_REP3) {
+            fetch_fe(ctx, l->buf[l->cur][1], 2, h);
+            fe_to_u64x4(h[0], out + 4);
+            fe_to_u64x4(h[1], out + 12);
+        } else {
+            for (int i = 0; i < 4; i++) out[4 + i] = out[12 + i] = 0;
+        }
+    });
+}
+
+// local half of layer_output / mul_vec: out[j] = L[j] x R[j] + mask_j (additive share c.a);
+// masked = 0 for the plain prover (then out IS the next layer).  The ring reshare that turns c.a
+// into (c.a, c.b = prev's c.a) is the network seam (cozk_layer_create on the two buffers).
+int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, uint64_t seed_self, uint64_t seed_prev,
+                            uint64_t counter, cozk_vec** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && out && l->len >= 2, "layer_output_local: bad argument");
+        size_t n = (l->len + 1) / 2;
+        fe* d = dev_alloc_fe(n);
+        const fe* a = l->buf[l->cur][0];
+        const fe* b = l->buf[l->cur][1];
+        if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
+        else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
+        HIP_TRY(hipGetLastError());
+        *out = new cozk_vec{ctx, n, COZK_SCALAR_FR, d, n * sizeof(fe), true};
+    });
+}
+
+// rep3::arithmetic::mul_vec local half on two share vectors (x, y given as SoA component vectors)
+int cozk_rep3_mul_vec_local(cozk_ctx* ctx, int mode, const cozk_vec* xa, const cozk_vec* xb, const cozk_vec* ya,
+                            const cozk_vec* yb, int masked, uint64_t seed_self, uint64_t seed_prev, uint64_t counter,
+                            cozk_vec** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && xa && ya && out && xa->n == ya->n && (mode == COZK_MODE_PLAIN || (xb && yb && xb->n == xa->n && yb->n == xa->n)),
+                     "mul_vec_local: bad argument");
+        size_t n = xa->n;
+        fe* d = dev_alloc_fe(n);
+        if (mode == COZK_MODE_REP3)
+            k_mul_vec_local<2><<<grid_for(n), PT, 0, ctx->stream>>>((const fe*)xa->d, (const fe*)xb->d, (const fe*)ya->d, (const fe*)yb->d, n, d, masked, seed_self, seed_prev, counter);
+        else
+            k_mul_vec_local<1><<<grid_for(n), PT, 0, ctx->stream>>>((const fe*)xa->d, nullptr, (const fe*)ya->d, nullptr, n, d, masked, seed_self, seed_prev, counter);
+        HIP_TRY(hipGetLastError());
+        *out = new cozk_vec{ctx, n, COZK_SCALAR_FR, d, n * sizeof(fe), true};
+    });
+}
+
+// claimed_outputs (grand_product.rs:266-272): last layer chunks(2) -> L x R, additive; out: n/2 x 4 u64
+int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && out && l->len >= 2 && l->len % 2 == 0, "claimed_outputs: bad argument");
+        size_t n = l->len / 2;
+        ctx->scratch.reserve(n * sizeof(fe));
+        fe* d = ctx->scratch.as<fe>();
+        const fe* a = l->buf[l->cur][0];
+        const fe* b = l->buf[l->cur][1];
+        if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, 0, 0, 0);
+        else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, 0, 0, 0);
+        HIP_TRY(hipGetLastError());
+        std::vector<fe> h(n);
+        fetch_fe(ctx, d, n, h.data());
+        for (size_t i = 0; i < n; i++) fe_to_u64x4(h[i], out + 4 * i);
+    });
+}
+
+}  // extern "C"

@@ -1,0 +1,301 @@
+"""Host-side mirror of the reference's polynomial interfaces over the C ABI:
+
+    Rep3DensePolynomial              co-jolt/src/poly/dense_mlpoly.rs
+    Rep3DenseInterleavedPolynomial   co-jolt/src/poly/dense_interleaved_poly.rs
+    SplitEqPolynomial                jolt-core (used dense_interleaved_poly.rs:218-303)
+
+`mode` = MODE_REP3 (shares {a, b}) or MODE_PLAIN (plain prover / public polynomial).
+Values cross as canonical Python ints; shares as (a, b) tuples.
+"""
+import ctypes
+
+import numpy as np
+
+from . import _lib as L
+from .engine import Vec, fr_to_mont_limbs, mont_limbs_to_int
+
+
+def _fr(x):
+    return fr_to_mont_limbs([x])[0]
+
+
+def _ptr_array(objs):
+    return (ctypes.c_void_p * len(objs))(*[o.h for o in objs])
+
+
+class Rep3DensePolynomial:
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.h = handle
+
+    # ---- constructors
+    @classmethod
+    def from_vec_shares(cls, ctx, a, b=None):
+        """`from_vec_shares(a, b)` (dense_mlpoly.rs:77-84); a, b: Vec (device) -- b None => plain"""
+        h = ctypes.c_void_p()
+        mode = L.MODE_REP3 if b is not None else L.MODE_PLAIN
+        ctx.check(ctx._l.cozk_poly_create(ctx.h, mode, a.h, b.h if b is not None else None, ctypes.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def new(cls, ctx, coeffs):
+        """`new(coeffs)`: list of (a, b) shares, or list of ints for a plain polynomial"""
+        if coeffs and isinstance(coeffs[0], tuple):
+            return cls.from_vec_shares(ctx, Vec.from_ints(ctx, [c[0] for c in coeffs]),
+                                       Vec.from_ints(ctx, [c[1] for c in coeffs]))
+        return cls.from_vec_shares(ctx, Vec.from_ints(ctx, coeffs))
+
+    @classmethod
+    def random(cls, ctx, n, seed, mode=L.MODE_REP3):
+        a = Vec.random(ctx, n, seed)
+        b = Vec.random(ctx, n, seed + 0x1000003) if mode == L.MODE_REP3 else None
+        return cls.from_vec_shares(ctx, a, b)
+
+    def chunk(self, offset, length):
+        """split_poly chunk view (dense_mlpoly.rs:275-301)"""
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_poly_chunk(self.ctx.h, self.h, offset, length, ctypes.byref(h)))
+        return Rep3DensePolynomial(self.ctx, h)
+
+    # ---- accessors
+    def __len__(self):
+        return self.ctx._l.cozk_poly_len(self.h)
+
+    def len(self):
+        return len(self)
+
+    @property
+    def mode(self):
+        return self.ctx._l.cozk_poly_mode(self.h)
+
+    def get_num_vars(self):
+        return len(self).bit_length() - 1
+
+    def coeffs(self):
+        n = len(self)
+        a = np.empty((n, 4), dtype=np.uint64)
+        b = np.empty((n, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_poly_download(self.ctx.h, self.h, a.ctypes.data, b.ctypes.data))
+        if self.mode == L.MODE_REP3:
+            return list(zip(mont_limbs_to_int(a), mont_limbs_to_int(b)))
+        return mont_limbs_to_int(a)
+
+    def copy_share_a(self):
+        """zero-copy device view of the `a` components (dense_mlpoly.rs:103-110)"""
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_poly_share_view(self.ctx.h, self.h, 0, ctypes.byref(h)))
+        v = Vec(self.ctx, h, L.SCALAR_FR)
+        v._keepalive = self
+        return v
+
+    def get_bound_coeff(self, index):
+        a = np.zeros(4, dtype=np.uint64)
+        b = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_poly_get_coeff(self.ctx.h, self.h, index, a.ctypes.data, b.ctypes.data))
+        if self.mode == L.MODE_REP3:
+            return (mont_limbs_to_int(a)[0], mont_limbs_to_int(b)[0])
+        return mont_limbs_to_int(a)[0]
+
+    def final_sumcheck_claim(self):
+        assert len(self) == 1
+        return self.get_bound_coeff(0)
+
+    # ---- PolynomialBinding
+    def bind(self, r, order):
+        rr = _fr(r)
+        self.ctx.check(self.ctx._l.cozk_poly_bind(self.ctx.h, self.h, rr.ctypes.data, order))
+
+    bind_parallel = bind
+
+    # ---- evaluation
+    @staticmethod
+    def batch_evaluate(polys, r):
+        """(dense_mlpoly.rs:183-192) -> (additive evals, eq Vec)"""
+        ctx = polys[0].ctx
+        eq = eq_evals(ctx, r)
+        return Rep3DensePolynomial.batch_evaluate_at_chi(polys, eq), eq
+
+    @staticmethod
+    def batch_evaluate_at_chi(polys, chi):
+        ctx = polys[0].ctx
+        k = len(polys)
+        out = np.zeros((k, 4), dtype=np.uint64)
+        ctx.check(ctx._l.cozk_poly_batch_evaluate_at_chi(ctx.h, _ptr_array(polys), k, chi.h, out.ctypes.data))
+        return mont_limbs_to_int(out)
+
+    def evaluate_at_chi(self, chi):
+        return Rep3DensePolynomial.batch_evaluate_at_chi([self], chi)[0]
+
+    def evaluate(self, r):
+        return Rep3DensePolynomial.batch_evaluate([self], r)[0][0]
+
+    def dot_product_with_public(self, other):
+        a = np.zeros(4, dtype=np.uint64)
+        b = np.zeros(4, dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_poly_dot_product_with_public(self.ctx.h, self.h, other.h, a.ctypes.data,
+                                                                     b.ctypes.data))
+        if self.mode == L.MODE_REP3:
+            return (mont_limbs_to_int(a)[0], mont_limbs_to_int(b)[0])
+        return mont_limbs_to_int(a)[0]
+
+    @staticmethod
+    def linear_combination(polys, coeffs, out_mode=None, party_id=0):
+        ctx = polys[0].ctx
+        if out_mode is None:
+            out_mode = L.MODE_REP3 if any(p.mode == L.MODE_REP3 for p in polys) else L.MODE_PLAIN
+        cf = fr_to_mont_limbs(coeffs)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._l.cozk_poly_linear_combination(ctx.h, _ptr_array(polys), cf.ctypes.data, len(polys), out_mode,
+                                                      party_id, ctypes.byref(h)))
+        return Rep3DensePolynomial(ctx, h)
+
+    def free(self):
+        if self.h:
+            self.ctx._l.cozk_poly_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def eq_evals(ctx, r):
+    """EqPolynomial::evals(r) as a device Vec"""
+    rr = fr_to_mont_limbs(r) if len(r) else np.zeros((0, 4), dtype=np.uint64)
+    h = ctypes.c_void_p()
+    ctx.check(ctx._l.cozk_eq_evals(ctx.h, rr.ctypes.data if len(r) else None, len(r), ctypes.byref(h)))
+    return Vec(ctx, h, L.SCALAR_FR)
+
+
+def open_quadratic_evals(polys, eqs):
+    """inner sums of compute_quadratic (opening_proof.rs:374-414) -> [(eval_0, eval_2)] additive"""
+    ctx = polys[0].ctx
+    k = len(polys)
+    out = np.zeros((2 * k, 4), dtype=np.uint64)
+    ctx.check(ctx._l.cozk_open_quadratic_evals(ctx.h, _ptr_array(polys), _ptr_array(eqs), k, out.ctypes.data))
+    v = mont_limbs_to_int(out)
+    return [(v[2 * i], v[2 * i + 1]) for i in range(k)]
+
+
+def pst_fold(ctx, r_vec, p, q_vec, r_next):
+    pp = _fr(p)
+    ctx.check(ctx._l.cozk_pst_fold(ctx.h, r_vec.h, pp.ctypes.data, q_vec.h, r_next.h))
+
+
+class SplitEqPolynomial:
+    def __init__(self, ctx, w):
+        self.ctx = ctx
+        ww = fr_to_mont_limbs(w) if len(w) else np.zeros((0, 4), dtype=np.uint64)
+        h = ctypes.c_void_p()
+        ctx.check(ctx._l.cozk_spliteq_new(ctx.h, ww.ctypes.data if len(w) else None, len(w), ctypes.byref(h)))
+        self.h = h
+        self.num_vars = len(w)
+
+    def get_num_vars(self):
+        return self.num_vars
+
+    def lens(self):
+        a = ctypes.c_size_t()
+        b = ctypes.c_size_t()
+        self.ctx._l.cozk_spliteq_lens(self.h, ctypes.byref(a), ctypes.byref(b))
+        return a.value, b.value
+
+    def bind(self, r):
+        rr = _fr(r)
+        self.ctx.check(self.ctx._l.cozk_spliteq_bind(self.ctx.h, self.h, rr.ctypes.data))
+
+    def free(self):
+        if self.h:
+            self.ctx._l.cozk_spliteq_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Rep3DenseInterleavedPolynomial:
+    def __init__(self, ctx, handle, mode):
+        self.ctx = ctx
+        self.h = handle
+        self.mode = mode
+
+    @classmethod
+    def from_vecs(cls, ctx, a, b=None, take_ownership=False):
+        mode = L.MODE_REP3 if b is not None else L.MODE_PLAIN
+        h = ctypes.c_void_p()
+        ctx.check(ctx._l.cozk_layer_create(ctx.h, mode, a.h, b.h if b is not None else None,
+                                           1 if take_ownership else 0, ctypes.byref(h)))
+        return cls(ctx, h, mode)
+
+    @classmethod
+    def new(cls, ctx, coeffs):
+        if coeffs and isinstance(coeffs[0], tuple):
+            return cls.from_vecs(ctx, Vec.from_ints(ctx, [c[0] for c in coeffs]), Vec.from_ints(ctx, [c[1] for c in coeffs]))
+        return cls.from_vecs(ctx, Vec.from_ints(ctx, coeffs))
+
+    def clone(self):
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_layer_clone(self.ctx.h, self.h, ctypes.byref(h)))
+        return Rep3DenseInterleavedPolynomial(self.ctx, h, self.mode)
+
+    def __len__(self):
+        return self.ctx._l.cozk_layer_len(self.h)
+
+    def len(self):
+        return len(self)
+
+    def coeffs(self):
+        n = len(self)
+        a = np.empty((n, 4), dtype=np.uint64)
+        b = np.empty((n, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_layer_download(self.ctx.h, self.h, a.ctypes.data, b.ctypes.data))
+        if self.mode == L.MODE_REP3:
+            return list(zip(mont_limbs_to_int(a), mont_limbs_to_int(b)))
+        return mont_limbs_to_int(a)
+
+    def bind(self, r, party_id=None):
+        rr = _fr(r)
+        self.ctx.check(self.ctx._l.cozk_layer_bind(self.ctx.h, self.h, rr.ctypes.data))
+
+    def compute_cubic(self, eq_poly, previous_round_claim, party_id=None):
+        """-> 4 additive coefficient shares (UniPoly<AdditiveShare>.coeffs)"""
+        pc = _fr(previous_round_claim)
+        out = np.zeros((4, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_layer_compute_cubic(self.ctx.h, self.h, eq_poly.h, pc.ctypes.data, out.ctypes.data))
+        return mont_limbs_to_int(out)
+
+    def final_claims(self, party_id=None):
+        out = np.zeros((4, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_layer_final_claims(self.ctx.h, self.h, out.ctypes.data))
+        v = mont_limbs_to_int(out)
+        if self.mode == L.MODE_REP3:
+            return (v[0], v[1]), (v[2], v[3])
+        return v[0], v[2]
+
+    def layer_output_local(self, masked=False, seed_self=0, seed_prev=0, counter=0):
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_layer_output_local(self.ctx.h, self.h, 1 if masked else 0, seed_self, seed_prev,
+                                                           counter, ctypes.byref(h)))
+        return Vec(self.ctx, h, L.SCALAR_FR)
+
+    def claimed_outputs(self):
+        n = len(self) // 2
+        out = np.zeros((n, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_layer_claimed_outputs(self.ctx.h, self.h, out.ctypes.data))
+        return mont_limbs_to_int(out)
+
+    def free(self):
+        if self.h:
+            self.ctx._l.cozk_layer_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

@@ -129,6 +129,79 @@ int cozk_g1_sum(cozk_ctx* ctx, const uint64_t* xy, const int* infinity, size_t k
 int cozk_g1_mul(cozk_ctx* ctx, const uint64_t xy[8], int infinity, const uint64_t s[4],
                 uint64_t out_xy[8], int* out_infinity);
 
+/* ---------------------------------------------------------------- polynomial seam ---------- */
+typedef struct cozk_poly cozk_poly;       /* Rep3DensePolynomial (co-jolt/src/poly/dense_mlpoly.rs:23-32); PLAIN = DensePolynomial */
+typedef struct cozk_layer cozk_layer;     /* Rep3DenseInterleavedPolynomial (co-jolt/src/poly/dense_interleaved_poly.rs:35-48) */
+typedef struct cozk_spliteq cozk_spliteq; /* SplitEqPolynomial (jolt-core; used dense_interleaved_poly.rs:218-303) */
+
+/* Rep3DensePolynomial::from_vec_shares(a, b) (dense_mlpoly.rs:77-84); b = NULL for MODE_PLAIN. Copies. */
+int cozk_poly_create(cozk_ctx* ctx, int mode, const cozk_vec* a, const cozk_vec* b, cozk_poly** out);
+/* split_poly: zero-copy chunk over the high variables (dense_mlpoly.rs:275-301) */
+int cozk_poly_chunk(cozk_ctx* ctx, const cozk_poly* src, size_t offset, size_t len, cozk_poly** out);
+int cozk_poly_free(cozk_poly* p);
+size_t cozk_poly_len(const cozk_poly* p);
+int cozk_poly_mode(const cozk_poly* p);
+/* current (bound) coefficients -> host; a, b = len x 4 u64 */
+int cozk_poly_download(cozk_ctx* ctx, const cozk_poly* p, uint64_t* a, uint64_t* b);
+/* copy_share_a (dense_mlpoly.rs:103-110) as a zero-copy view: component 0 = a, 1 = b */
+int cozk_poly_share_view(cozk_ctx* ctx, const cozk_poly* p, int component, cozk_vec** out);
+/* PolynomialBinding::bind / bind_parallel (dense_mlpoly.rs:310-459) */
+int cozk_poly_bind(cozk_ctx* ctx, cozk_poly* p, const uint64_t r[4], int order);
+/* get_bound_coeff / final_sumcheck_claim (dense_mlpoly.rs:251-257,461-465) */
+int cozk_poly_get_coeff(cozk_ctx* ctx, const cozk_poly* p, size_t index, uint64_t a[4], uint64_t b[4]);
+/* EqPolynomial::evals(r) on device, big-endian (use: dense_mlpoly.rs:149-153,183-185) */
+int cozk_eq_evals(cozk_ctx* ctx, const uint64_t* r, int nv, cozk_vec** out);
+/* batch_evaluate / evaluate_at_chi (dense_mlpoly.rs:160-192): out[k] = additive share of poly_k . chi */
+int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys, size_t k,
+                                    const cozk_vec* chi, uint64_t* out);
+/* dot_product_with_public (dense_mlpoly.rs:228-234) -> share (a, b) */
+int cozk_poly_dot_product_with_public(cozk_ctx* ctx, const cozk_poly* p, const cozk_vec* pub,
+                                      uint64_t a[4], uint64_t b[4]);
+/* linear_combination (dense_mlpoly.rs:195-226; multilinear_polynomial.rs:196-296); PLAIN inputs in a
+ * REP3 combination are public polynomials added via add_public for `party_id` */
+int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, const uint64_t* coeffs,
+                                 size_t k, int out_mode, int party_id, cozk_poly** out);
+/* compute_quadratic inner sums for the live openings of one round (opening_proof.rs:374-414):
+ * out[2i] = eval_0, out[2i+1] = eval_2 (additive) */
+int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys,
+                              const cozk_poly* const* eqs, size_t k, uint64_t* out);
+/* one fold of PST13 `open` (pst13.rs:445-459): q[b] = r[2b+1]-r[2b]; r'[b] = r[2b](1-p) + r[2b+1]p */
+int cozk_pst_fold(cozk_ctx* ctx, const cozk_vec* r, const uint64_t p[4], cozk_vec* q, cozk_vec* r_next);
+
+/* Rep3DenseInterleavedPolynomial::new (dense_interleaved_poly.rs:61-75); take_ownership != 0 adopts
+ * the vectors' device buffers instead of copying (the vectors become empty views) */
+int cozk_layer_create(cozk_ctx* ctx, int mode, const cozk_vec* a, const cozk_vec* b,
+                      int take_ownership, cozk_layer** out);
+int cozk_layer_free(cozk_layer* l);
+size_t cozk_layer_len(const cozk_layer* l);
+int cozk_layer_download(cozk_ctx* ctx, const cozk_layer* l, uint64_t* a, uint64_t* b);
+int cozk_layer_clone(cozk_ctx* ctx, const cozk_layer* src, cozk_layer** out);
+/* Rep3Bindable::bind (dense_interleaved_poly.rs:155-195) */
+int cozk_layer_bind(cozk_ctx* ctx, cozk_layer* l, const uint64_t r[4]);
+/* Rep3BatchedCubicSumcheckWorker::compute_cubic (dense_interleaved_poly.rs:210-365): 4 additive
+ * coefficient shares (low -> high) of the round polynomial */
+int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,
+                             const uint64_t prev_claim[4], uint64_t out_coeffs[16]);
+/* final_claims (dense_interleaved_poly.rs:367-372): out = L.a, L.b, R.a, R.b (b = 0 for PLAIN) */
+int cozk_layer_final_claims(cozk_ctx* ctx, const cozk_layer* l, uint64_t out[16]);
+/* local half of layer_output -> mul_vec (dense_interleaved_poly.rs:122-141; local product
+ * mpc-types/src/protocols/rep3/arithmetic/ops.rs:71-78): out[j] = L[j] x R[j] + mask_j, where
+ * mask_j = PRF(seed_self, counter + j) - PRF(seed_prev, counter + j) when masked != 0 */
+int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, uint64_t seed_self,
+                            uint64_t seed_prev, uint64_t counter, cozk_vec** out);
+/* rep3::arithmetic::mul_vec, local half, on SoA share vectors */
+int cozk_rep3_mul_vec_local(cozk_ctx* ctx, int mode, const cozk_vec* xa, const cozk_vec* xb,
+                            const cozk_vec* ya, const cozk_vec* yb, int masked, uint64_t seed_self,
+                            uint64_t seed_prev, uint64_t counter, cozk_vec** out);
+/* claimed_outputs (grand_product.rs:266-272): out = (len/2) x 4 u64 additive products */
+int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out);
+
+/* SplitEqPolynomial::{new, bind} */
+int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out);
+int cozk_spliteq_free(cozk_spliteq* e);
+int cozk_spliteq_lens(const cozk_spliteq* e, size_t* e1_len, size_t* e2_len);
+int cozk_spliteq_bind(cozk_ctx* ctx, cozk_spliteq* e, const uint64_t r[4]);
+
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation) on the ctx stream, for
  * bench.py's roofline object: launches, total ms, point additions issued. */
