@@ -9,3 +9,4 @@ from .engine import (Context, Vec, Bases, FR_MOD, FQ_MOD, fr_to_mont_limbs, mont
                      point_to_abi, point_from_abi)
 from .poly import (Rep3DensePolynomial, Rep3DenseInterleavedPolynomial, SplitEqPolynomial, eq_evals,
                    open_quadratic_evals, pst_fold)
+from .harness import Harness, HarnessConfig, HarnessResult

@@ -72,6 +72,7 @@ SIGNATURES = {
     "cozk_msm": (_i, [_vp, _vp, _sz, _vp, _i, _sz, _vp, ctypes.POINTER(_i)]),
     "cozk_msm_vec": (_i, [_vp, _vp, _sz, _vp, _vp, ctypes.POINTER(_i)]),
     "cozk_batch_msm_vec": (_i, [_vp, _vp, _sz, _vp, _sz, _vp, _vp]),
+    "cozk_batch_msm_slices": (_i, [_vp, _vp, _vp, _vp, _vp, _sz, _vp, _vp]),
     "cozk_g1_sum": (_i, [_vp, _vp, _vp, _sz, _vp, ctypes.POINTER(_i)]),
     "cozk_g1_mul": (_i, [_vp, _vp, _i, _vp, _vp, ctypes.POINTER(_i)]),
     "cozk_poly_create": (_i, [_vp, _i, _vp, _vp, _pp]),

@@ -1,0 +1,701 @@
+// In-process harness: the counterpart of the reference's runner (co-jolt/examples/rep3_jolt.rs:118-317
+// + run_3_party_jolt.sh) for the hot path.  From a seed it (i) synthesises the witness polynomials of
+// one trace, (ii) shares them Rep3 (mpc-core/.../arithmetic.rs:21-33) or
+// keeps them plain, (iii) runs on one worker thread per party (one ctx / HIP stream each):
+//       commit -> dense grand product (construct + prove) -> batch_evaluate + append -> reduce_and_prove
+//     while the calling thread plays the coordinator (transcript owner), and (iv) verifies:
+//     GKR proof, final GKR claim == direct leaf evaluation, opening-reduction sumcheck, PST opening
+//     (pairing-free, trapdoor known).  Setup (SRS + witness resident in HBM) is separate from the
+//     timed `prove` step.
+#include <chrono>
+#include <thread>
+
+#include "host/prover.hpp"
+
+using namespace cozk;
+
+static uint64_t sm_next_host(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// element i of the stream `seed` (same generator as cozk_vec_fill_random / oracle synthetic_fr)
+static fe synthetic_fr_host(uint64_t seed, uint64_t i) {
+    uint64_t s = seed + i * 0xD1342543DE82EF95ull;
+    fe v;
+    for (;;) {
+        uint64_t w0 = sm_next_host(s), w1 = sm_next_host(s), w2 = sm_next_host(s), w3 = sm_next_host(s) & ((1ull << 62) - 1ull);
+        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
+        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
+        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
+        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
+        if (!Fr::geq_mod(v)) break;
+    }
+    return Fr::to_mont(v);
+}
+
+__global__ void k_small_to_fr_u8(const uint8_t* in, fe* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(out + i, Fr::from_u64(in[i]));
+}
+__global__ void k_small_to_fr_u16(const uint16_t* in, fe* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(out + i, Fr::from_u64(in[i]));
+}
+__global__ void k_small_to_fr_u32(const uint32_t* in, fe* out, size_t n) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(out + i, Fr::from_u64(in[i]));
+}
+
+namespace {
+
+struct PartyState {
+    cozk_ctx* ctx = nullptr;
+    bool own_ctx = false;
+    int party = 0;
+    // committed polynomials in commit order: first the shared (FR) ones, then the public ones
+    std::vector<PolyH> polys;        // evaluation view (REP3 shares, or PLAIN Fr values for public polys)
+    std::vector<VecH> commit_vecs;   // what the MSM consumes: share-a view (FR) or the compact small-scalar vector
+    std::vector<int> is_public;
+    std::vector<PolyH> small_polys;  // shared polynomials of length N / 16 ("final_cts"-like)
+    std::vector<VecH> small_commit_vecs;
+    LayerH leaves;                   // grand-product leaves (kept intact; each prove works on a clone)
+    std::unique_ptr<PST13Setup> setup;
+    // per-phase wall times of the last prove (ms)
+    double t_commit = 0, t_construct = 0, t_gp = 0, t_eval = 0, t_open = 0, t_total = 0;
+    uint64_t star_up = 0, star_down = 0, ring_bytes = 0, star_msgs = 0;
+    std::string error;
+};
+
+struct ProofBundle {
+    std::vector<PST13Commitment> commitments, small_commitments;
+    GrandProductProof gp;
+    std::vector<std::vector<fe>> opening_claims;  // per append
+    ReducedOpeningProof reduced;
+    Bytes serialize() const {
+        Writer w;
+        w.u64(commitments.size());
+        for (auto& c : commitments) {
+            w.u64(c.nv);
+            w.g1(c.g_product);
+        }
+        w.u64(small_commitments.size());
+        for (auto& c : small_commitments) {
+            w.u64(c.nv);
+            w.g1(c.g_product);
+        }
+        w.vec_fr(gp.outputs);
+        w.u64(gp.gkr_layers.size());
+        for (auto& l : gp.gkr_layers) {
+            w.u64(l.proof.compressed_polys.size());
+            for (auto& p : l.proof.compressed_polys) w.vec_fr(p);
+            w.fr(l.left_claim);
+            w.fr(l.right_claim);
+        }
+        w.u64(opening_claims.size());
+        for (auto& c : opening_claims) w.vec_fr(c);
+        w.u64(reduced.sumcheck_proof.compressed_polys.size());
+        for (auto& p : reduced.sumcheck_proof.compressed_polys) w.vec_fr(p);
+        w.vec_fr(reduced.sumcheck_claims);
+        w.vec_g1(reduced.joint_opening_proof);
+        return w.b;
+    }
+};
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+}  // namespace
+
+struct cozk_harness {
+    cozk_harness_config cfg;
+    int nparties = 1;
+    size_t N = 0;
+    std::vector<PartyState> parties;
+    std::string error;
+    Bytes last_proof;
+};
+
+// --------------------------------------------------------------------------- setup
+static VecH make_vec_random(cozk_ctx* ctx, size_t n, int kind, uint64_t seed, int bits) {
+    cozk_vec* v = nullptr;
+    rc_check(cozk_vec_alloc(ctx, n, kind, &v), ctx, "vec_alloc");
+    VecH h(v);
+    rc_check(cozk_vec_fill_random(ctx, v, seed, bits), ctx, "fill_random");
+    return h;
+}
+static VecH vec_binop(cozk_ctx* ctx, int op, const VecH& a, const VecH& b) {
+    cozk_vec* o = nullptr;
+    rc_check(cozk_vec_alloc(ctx, cozk_vec_len(a.h), COZK_SCALAR_FR, &o), ctx, "vec_alloc");
+    VecH h(o);
+    rc_check(cozk_vec_binop(ctx, op, 0, a.h, b.h, o), ctx, "vec_binop");
+    return h;
+}
+
+// share components of the secret vector stream(seed): P0 = (t0, t2), P1 = (t1, t0), P2 = (t2, t1)
+// with t0 = stream(seed+1), t1 = stream(seed+2), t2 = v - t0 - t1 (arithmetic.rs:21-33)
+static void make_share_vectors(cozk_ctx* ctx, size_t n, uint64_t seed, int party, int mode, VecH& a, VecH& b) {
+    if (mode == COZK_MODE_PLAIN) {
+        a = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
+        return;
+    }
+    VecH v = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
+    VecH t0 = make_vec_random(ctx, n, COZK_SCALAR_FR, seed + 1, 0);
+    VecH t1 = make_vec_random(ctx, n, COZK_SCALAR_FR, seed + 2, 0);
+    VecH d = vec_binop(ctx, COZK_OP_SUB, v, t0);
+    VecH t2 = vec_binop(ctx, COZK_OP_SUB, d, t1);
+    if (party == 0) {
+        a = std::move(t0);
+        b = std::move(t2);
+    } else if (party == 1) {
+        a = std::move(t1);
+        b = std::move(t0);
+    } else {
+        a = std::move(t2);
+        b = std::move(t1);
+    }
+}
+
+static void setup_party(cozk_harness* h, PartyState& ps) {
+    const cozk_harness_config& c = h->cfg;
+    cozk_ctx* ctx = ps.ctx;
+    size_t N = h->N;
+    int nv = c.log_n;
+    // SRS from the seeded trapdoor
+    std::vector<fe> t(nv);
+    for (int i = 0; i < nv; i++) t[i] = synthetic_fr_host(c.seed ^ 0x7A7A7A7Aull, (uint64_t)i);
+    ps.setup = PST13::setup(ctx, t, c.precompute);
+    int j = 0;
+    for (int k = 0; k < c.n_fr; k++, j++) {
+        VecH a, b;
+        make_share_vectors(ctx, N, c.seed + 1000ull * (uint64_t)(j + 1), ps.party, c.mode, a, b);
+        cozk_poly* p = nullptr;
+        rc_check(cozk_poly_create(ctx, c.mode, a.h, b.h, &p), ctx, "poly_create");
+        ps.polys.push_back(PolyH(p));
+        cozk_vec* view = nullptr;
+        rc_check(cozk_poly_share_view(ctx, p, 0, &view), ctx, "share_view");
+        ps.commit_vecs.push_back(VecH(view));
+        ps.is_public.push_back(0);
+    }
+    struct SmallSpec { int count, kind, bits; };
+    SmallSpec specs[3] = {{c.n_u16, COZK_SCALAR_U16, 0}, {c.n_u32, COZK_SCALAR_U32, 0}, {c.n_flags, COZK_SCALAR_U8, 1}};
+    for (auto& sp : specs) {
+        for (int k = 0; k < sp.count; k++, j++) {
+            VecH sv = make_vec_random(ctx, N, sp.kind, c.seed + 1000ull * (uint64_t)(j + 1), sp.bits);
+            cozk_vec* frv = nullptr;
+            rc_check(cozk_vec_alloc(ctx, N, COZK_SCALAR_FR, &frv), ctx, "vec_alloc");
+            VecH fr(frv);
+            unsigned grid = (unsigned)((N + 255) / 256);
+            if (sp.kind == COZK_SCALAR_U8) k_small_to_fr_u8<<<grid, 256, 0, ctx->stream>>>((const uint8_t*)cozk_vec_device_ptr(sv.h), (fe*)cozk_vec_device_ptr(fr.h), N);
+            else if (sp.kind == COZK_SCALAR_U16) k_small_to_fr_u16<<<grid, 256, 0, ctx->stream>>>((const uint16_t*)cozk_vec_device_ptr(sv.h), (fe*)cozk_vec_device_ptr(fr.h), N);
+            else k_small_to_fr_u32<<<grid, 256, 0, ctx->stream>>>((const uint32_t*)cozk_vec_device_ptr(sv.h), (fe*)cozk_vec_device_ptr(fr.h), N);
+            HIP_TRY(hipGetLastError());
+            cozk_poly* p = nullptr;
+            rc_check(cozk_poly_create(ctx, COZK_MODE_PLAIN, fr.h, nullptr, &p), ctx, "poly_create");
+            ps.polys.push_back(PolyH(p));
+            ps.commit_vecs.push_back(std::move(sv));
+            ps.is_public.push_back(1);
+        }
+    }
+    if (c.n_small > 0) {
+        COZK_REQUIRE(c.log_n >= 5, "n_small needs log_n >= 5");
+        size_t M = N >> 4;
+        for (int k = 0; k < c.n_small; k++) {
+            VecH a, b;
+            make_share_vectors(ctx, M, c.seed + 300000ull + 1000ull * (uint64_t)k, ps.party, c.mode, a, b);
+            cozk_poly* p = nullptr;
+            rc_check(cozk_poly_create(ctx, c.mode, a.h, b.h, &p), ctx, "poly_create");
+            ps.small_polys.push_back(PolyH(p));
+            cozk_vec* view = nullptr;
+            rc_check(cozk_poly_share_view(ctx, p, 0, &view), ctx, "share_view");
+            ps.small_commit_vecs.push_back(VecH(view));
+        }
+    }
+    // grand-product leaves: gp_batch circuits x 2^gp_log_leaves interleaved entries
+    size_t nleaves = (size_t)c.gp_batch << c.gp_log_leaves;
+    VecH la, lb;
+    make_share_vectors(ctx, nleaves, c.seed + 500000ull, ps.party, c.mode, la, lb);
+    cozk_layer* lv = nullptr;
+    rc_check(cozk_layer_create(ctx, c.mode, la.h, lb.h, 1, &lv), ctx, "layer_create");
+    ps.leaves = LayerH(lv);
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+}
+
+// --------------------------------------------------------------------------- worker
+static void put_commitments(Writer& w, const std::vector<PST13Commitment>& cs, const std::vector<int>& is_public, int party) {
+    w.u64(cs.size());
+    for (size_t i = 0; i < cs.size(); i++) {
+        // MaybeShared tag: 0 Public(None), 1 Public(Some), 2 Shared (pst13.rs:140-162)
+        uint8_t tag = is_public[i] ? (party == 0 ? 1 : 0) : 2;
+        w.b.push_back(tag);
+        if (tag != 0) {
+            w.u64(cs[i].nv);
+            w.g1(cs[i].g_product);
+        }
+    }
+}
+
+static void worker_main(cozk_harness* h, PartyState& ps, StarNetWorker* star, RingNet* ring) {
+    const cozk_harness_config& c = h->cfg;
+    WorkerEnv env;
+    env.ctx = ps.ctx;
+    env.mode = c.mode;
+    env.party = ps.party;
+    env.star = star;
+    env.ring = ring;
+    env.seed_self = c.seed + 900000ull + (uint64_t)ps.party;
+    env.seed_prev = c.seed + 900000ull + (uint64_t)((ps.party + 2) % 3);
+    HIP_TRY(hipSetDevice(ps.ctx->device));
+    double t_start = now_ms();
+    // ---- 1. commit (Rep3JoltPolynomials::commit, jolt/vm/jolt/witness.rs:304-382): every party MSMs
+    //         every polynomial; only P0's public commitments are kept (pst13.rs:165-229)
+    {
+        std::vector<cozk_vec*> vs;
+        for (auto& v : ps.commit_vecs) vs.push_back(v.h);
+        std::vector<PST13Commitment> cm = PST13::batch_commit(ps.ctx, *ps.setup, vs);
+        std::vector<cozk_vec*> sv;
+        for (auto& v : ps.small_commit_vecs) sv.push_back(v.h);
+        std::vector<PST13Commitment> scm = PST13::batch_commit(ps.ctx, *ps.setup, sv);
+        Writer w;
+        put_commitments(w, cm, ps.is_public, ps.party);
+        std::vector<int> none(scm.size(), 0);
+        put_commitments(w, scm, none, ps.party);
+        star->send_response(w.b);
+    }
+    double t1 = now_ms();
+    ps.t_commit = t1 - t_start;
+    // ---- 2. dense grand product (memory-checking shape, lasso/memory_checking/worker.rs:77-127)
+    cozk_layer* lv = nullptr;
+    rc_check(cozk_layer_clone(ps.ctx, ps.leaves.h, &lv), ps.ctx, "layer_clone");  // stand-in for compute_leaves
+    Rep3BatchedDenseGrandProduct gp = Rep3BatchedDenseGrandProduct::construct(env, LayerH(lv), (size_t)c.gp_batch);
+    HIP_TRY(hipStreamSynchronize(ps.ctx->stream));
+    double t2 = now_ms();
+    ps.t_construct = t2 - t1;
+    std::vector<fe> r_gp = gp.prove_grand_product_worker(env);
+    double t3 = now_ms();
+    ps.t_gp = t3 - t2;
+    // harness check message (not part of the proof): additive share of leaves(r_gp)
+    {
+        // the original leaves as a dense polynomial over (circuit, position, l/r) variables
+        std::vector<uint64_t> rr = to_abi(r_gp);
+        cozk_vec* chi = nullptr;
+        rc_check(cozk_eq_evals(ps.ctx, rr.data(), (int)r_gp.size(), &chi), ps.ctx, "eq_evals");
+        VecH chih(chi);
+        cozk_poly* lp = nullptr;
+        rc_check(cozk_layer_as_poly(ps.ctx, ps.leaves.h, &lp), ps.ctx, "layer_as_poly");
+        PolyH lph(lp);
+        uint64_t ev[4];
+        const cozk_poly* arr[1] = {lph.h};
+        rc_check(cozk_poly_batch_evaluate_at_chi(ps.ctx, arr, 1, chih.h, ev), ps.ctx, "leaf evaluation");
+        Writer w;
+        w.fr(fe_from_u64x4(ev));
+        star->send_response(w.b);
+    }
+    // ---- 3. openings: batch_evaluate + append (compute_openings -> opening_accumulator.append)
+    Rep3ProverOpeningAccumulator acc;
+    size_t K = ps.polys.size();
+    size_t half = (K + 1) / 2;
+    int nv = c.log_n;
+    auto open_group = [&](size_t lo, size_t hi, const std::vector<fe>& point, std::vector<PolyH>& src) {
+        if (hi <= lo) return;
+        std::vector<uint64_t> rr = to_abi(point);
+        cozk_vec* chi = nullptr;
+        rc_check(cozk_eq_evals(ps.ctx, rr.data(), (int)point.size(), &chi), ps.ctx, "eq_evals");
+        VecH chih(chi);
+        // shared and public polynomials evaluate in their own batches (additive vs trivial share)
+        std::vector<cozk_poly*> ps_all;
+        std::vector<fe> claims(hi - lo);
+        std::vector<const cozk_poly*> shp, pbp;
+        std::vector<size_t> shi, pbi;
+        for (size_t i = lo; i < hi; i++) {
+            ps_all.push_back(src[i].h);
+            if (cozk_poly_mode(src[i].h) == c.mode) {
+                shp.push_back(src[i].h);
+                shi.push_back(i - lo);
+            } else {
+                pbp.push_back(src[i].h);
+                pbi.push_back(i - lo);
+            }
+        }
+        if (!shp.empty()) {
+            std::vector<uint64_t> out(4 * shp.size());
+            rc_check(cozk_poly_batch_evaluate_at_chi(ps.ctx, shp.data(), shp.size(), chih.h, out.data()), ps.ctx, "batch_evaluate");
+            for (size_t k = 0; k < shp.size(); k++) claims[shi[k]] = fe_from_u64x4(out.data() + 4 * k);
+        }
+        if (!pbp.empty()) {
+            std::vector<uint64_t> out(4 * pbp.size());
+            rc_check(cozk_poly_batch_evaluate_at_chi(ps.ctx, pbp.data(), pbp.size(), chih.h, out.data()), ps.ctx, "batch_evaluate(public)");
+            // a public evaluation is held by P0 only (additive::promote_to_trivial_share)
+            for (size_t k = 0; k < pbp.size(); k++) claims[pbi[k]] = env.additive_trivial(fe_from_u64x4(out.data() + 4 * k));
+        }
+        acc.append(env, ps_all, chih.h, point, claims);
+    };
+    {
+        std::vector<fe> p1(r_gp.end() - nv, r_gp.end());
+        std::vector<fe> p2(r_gp.begin(), r_gp.begin() + nv);
+        open_group(0, half, p1, ps.polys);
+        open_group(half, K, p2, ps.polys);
+        if (!ps.small_polys.empty()) {
+            std::vector<fe> p3(r_gp.end() - (nv - 4), r_gp.end());
+            open_group(0, ps.small_polys.size(), p3, ps.small_polys);
+        }
+    }
+    double t4 = now_ms();
+    ps.t_eval = t4 - t3;
+    // ---- 4. reduce_and_prove_worker (opening_proof.rs:238-291)
+    acc.reduce_and_prove_worker(env, *ps.setup);
+    double t5 = now_ms();
+    ps.t_open = t5 - t4;
+    ps.t_total = t5 - t_start;
+    ps.star_up = star->bytes_up;
+    ps.star_down = star->bytes_down;
+    ps.star_msgs = star->n_msgs;
+    ps.ring_bytes = ring ? ring->bytes_sent : 0;
+}
+
+// --------------------------------------------------------------------------- coordinator + verifier
+static std::vector<PST13Commitment> combine_commitments_from_parties(std::vector<Reader>& rds, int nparties) {
+    std::vector<PST13Commitment> out;
+    uint64_t n = 0;
+    for (int p = 0; p < nparties; p++) {
+        uint64_t m = rds[p].u64();
+        if (p == 0) n = m;
+        if (m != n) throw CozkError(COZK_ERR_INTERNAL, "commitment count mismatch");
+    }
+    for (uint64_t i = 0; i < n; i++) {
+        std::vector<PST13Commitment> shares;
+        bool have_public = false;
+        PST13Commitment pub{};
+        for (int p = 0; p < nparties; p++) {
+            rds[p].need(1);
+            uint8_t tag = *rds[p].p++;
+            if (tag == 0) continue;
+            PST13Commitment c;
+            c.nv = rds[p].u64();
+            c.g_product = rds[p].g1();
+            if (tag == 1) {
+                have_public = true;
+                pub = c;
+            } else {
+                shares.push_back(c);
+            }
+        }
+        if (have_public) out.push_back(pub);
+        else out.push_back(PST13::combine_commitment_shares(shares));
+    }
+    return out;
+}
+
+static fe eq_eval(const std::vector<fe>& a, const std::vector<fe>& b) {
+    fe one = Fr::one(), acc = one;
+    for (size_t i = 0; i < a.size(); i++) {
+        fe ab = Fr::mul(a[i], b[i]);
+        acc = Fr::mul(acc, Fr::add(Fr::sub(Fr::sub(one, a[i]), b[i]), Fr::dbl(ab)));
+    }
+    return acc;
+}
+
+static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundle& proof, bool verify, std::string& why) {
+    const cozk_harness_config& c = h->cfg;
+    int np = h->nparties;
+    int nv = c.log_n;
+    Transcript tr("cozk-harness");
+    // receive_commitments (jolt/vm/jolt/witness.rs:221-285)
+    {
+        std::vector<Bytes> msgs = net.receive_responses();
+        std::vector<Reader> rds;
+        for (auto& m : msgs) rds.emplace_back(m);
+        proof.commitments = combine_commitments_from_parties(rds, np);
+        proof.small_commitments = combine_commitments_from_parties(rds, np);
+        for (auto& cm : proof.commitments) tr.append_point(cm.g_product);
+        for (auto& cm : proof.small_commitments) tr.append_point(cm.g_product);
+    }
+    fe gp_claim;
+    std::vector<fe> r_gp;
+    size_t num_layers = (size_t)c.gp_log_leaves;
+    proof.gp = coordinate_prove_grand_product(net, tr, num_layers, gp_claim, r_gp);
+    // harness check: sum of the parties' additive leaf evaluations
+    fe leaf_eval = Fr::zero();
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        leaf_eval = Fr::add(leaf_eval, rd.fr());
+    }
+    size_t K = proof.commitments.size();
+    size_t half = (K + 1) / 2;
+    int nappend = 2 + (c.n_small > 0 ? 1 : 0);
+    if (half >= K) nappend -= 1;
+    Transcript tr_open_start = tr;  // the verifier replays from here
+    std::vector<fe> rhos;
+    for (int a = 0; a < nappend; a++) {
+        Transcript before = tr;
+        proof.opening_claims.push_back(Rep3ProverOpeningAccumulator::receive_claims(net, tr));
+        (void)before;
+    }
+    std::vector<fe> r_red;
+    fe rho_red, gamma;
+    proof.reduced = Rep3ProverOpeningAccumulator::reduce_and_prove(net, tr, r_red, rho_red, gamma);
+    if (!verify) return -1;
+
+    // ------------------------------------------------ plain verifier (replays its own transcript)
+    Transcript vt("cozk-harness");
+    for (auto& cm : proof.commitments) vt.append_point(cm.g_product);
+    for (auto& cm : proof.small_commitments) vt.append_point(cm.g_product);
+    fe v_claim;
+    std::vector<fe> v_r;
+    if (!verify_grand_product(proof.gp, vt, v_claim, v_r)) {
+        why = "GKR proof rejected";
+        return 0;
+    }
+    if (v_r.size() != r_gp.size() || !Fr::eq(v_claim, gp_claim)) {
+        why = "GKR verifier / coordinator disagree";
+        return 0;
+    }
+    if (!Fr::eq(v_claim, leaf_eval)) {
+        why = "final GKR claim != direct evaluation of the leaves";
+        return 0;
+    }
+    // openings: points as the workers chose them
+    struct VOpen { std::vector<fe> point; std::vector<g1_affine> cs; std::vector<fe> claims; fe rho; };
+    std::vector<VOpen> vo;
+    {
+        std::vector<fe> p1(v_r.end() - nv, v_r.end()), p2(v_r.begin(), v_r.begin() + nv);
+        VOpen o1;
+        o1.point = p1;
+        for (size_t i = 0; i < half; i++) o1.cs.push_back(proof.commitments[i].g_product);
+        vo.push_back(o1);
+        if (half < K) {
+            VOpen o2;
+            o2.point = p2;
+            for (size_t i = half; i < K; i++) o2.cs.push_back(proof.commitments[i].g_product);
+            vo.push_back(o2);
+        }
+        if (c.n_small > 0) {
+            VOpen o3;
+            o3.point.assign(v_r.end() - (nv - 4), v_r.end());
+            for (auto& cm : proof.small_commitments) o3.cs.push_back(cm.g_product);
+            vo.push_back(o3);
+        }
+    }
+    if (vo.size() != proof.opening_claims.size()) {
+        why = "opening count mismatch";
+        return 0;
+    }
+    std::vector<fe> batched_claims;
+    std::vector<g1_affine> batched_commitments;
+    for (size_t a = 0; a < vo.size(); a++) {
+        vo[a].claims = proof.opening_claims[a];
+        if (vo[a].claims.size() != vo[a].cs.size()) {
+            why = "claims / commitments mismatch";
+            return 0;
+        }
+        vo[a].rho = vt.challenge_scalar();
+        std::vector<fe> pw(1, Fr::one());
+        for (size_t i = 1; i < vo[a].claims.size(); i++) pw.push_back(Fr::mul(pw[i - 1], vo[a].rho));
+        fe bc = Fr::zero();
+        for (size_t i = 0; i < pw.size(); i++) bc = Fr::add(bc, Fr::mul(pw[i], vo[a].claims[i]));
+        batched_claims.push_back(bc);
+        batched_commitments.push_back(PST13::combine_commitments(vo[a].cs, pw));
+    }
+    // reduction sumcheck
+    fe rho2 = vt.challenge_scalar();
+    size_t max_nv = 0;
+    for (auto& o : vo) max_nv = std::max(max_nv, o.point.size());
+    std::vector<fe> coeffs(1, Fr::one());
+    for (size_t i = 1; i < vo.size(); i++) coeffs.push_back(Fr::mul(coeffs[i - 1], rho2));
+    fe e = Fr::zero();
+    for (size_t i = 0; i < vo.size(); i++)
+        e = Fr::add(e, Fr::mul(coeffs[i], Fr::mul(batched_claims[i], fr_from_u64((uint64_t)1 << (max_nv - vo[i].point.size())))));
+    std::vector<fe> rs;
+    if (proof.reduced.sumcheck_proof.compressed_polys.size() != max_nv) {
+        why = "reduction sumcheck: wrong number of rounds";
+        return 0;
+    }
+    for (auto& comp : proof.reduced.sumcheck_proof.compressed_polys) {
+        std::vector<fe> poly = unipoly_decompress(comp, e);
+        vt.append_scalars(comp);
+        fe r_j = vt.challenge_scalar();
+        rs.push_back(r_j);
+        e = unipoly_eval(poly, r_j);
+    }
+    fe expect = Fr::zero();
+    for (size_t i = 0; i < vo.size(); i++) {
+        std::vector<fe> slice(rs.end() - vo[i].point.size(), rs.end());
+        expect = Fr::add(expect, Fr::mul(coeffs[i], Fr::mul(eq_eval(vo[i].point, slice), proof.reduced.sumcheck_claims[i])));
+    }
+    if (!Fr::eq(expect, e)) {
+        why = "reduction sumcheck: final check failed";
+        return 0;
+    }
+    vt.append_scalars(proof.reduced.sumcheck_claims);
+    fe vgamma = vt.challenge_scalar();
+    // joint commitment / claim
+    std::vector<fe> gp_pw(1, Fr::one());
+    for (size_t i = 1; i < vo.size(); i++) gp_pw.push_back(Fr::mul(gp_pw[i - 1], vgamma));
+    g1_affine joint_c = PST13::combine_commitments(batched_commitments, gp_pw);
+    fe joint_claim = Fr::zero();
+    fe one = Fr::one();
+    for (size_t i = 0; i < vo.size(); i++) {
+        fe sc = one;
+        for (size_t j = 0; j + vo[i].point.size() < max_nv; j++) sc = Fr::mul(sc, Fr::sub(one, rs[j]));
+        joint_claim = Fr::add(joint_claim, Fr::mul(gp_pw[i], Fr::mul(sc, proof.reduced.sumcheck_claims[i])));
+    }
+    std::vector<fe> rev(rs.rbegin(), rs.rend());
+    if (!PST13::check_with_trapdoor(*h->parties[0].setup, joint_c, rev, joint_claim, proof.reduced.joint_opening_proof)) {
+        why = "PST13 opening check failed";
+        return 0;
+    }
+    (void)tr_open_start;
+    (void)rho_red;
+    (void)gamma;
+    (void)r_red;
+    return 1;
+}
+
+// --------------------------------------------------------------------------- C ABI
+extern "C" {
+
+int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out) {
+    if (!cfg || !out) return COZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    cozk_harness* h = new cozk_harness();
+    h->cfg = *cfg;
+    try {
+        COZK_REQUIRE(cfg->mode == COZK_MODE_PLAIN || cfg->mode == COZK_MODE_REP3, "harness: bad mode");
+        COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24, "harness: log_n out of range");
+        COZK_REQUIRE(cfg->gp_batch >= 1 && cfg->gp_log_leaves >= 1, "harness: bad grand-product shape");
+        int gbits = 0;
+        while ((1 << gbits) < cfg->gp_batch) gbits++;
+        COZK_REQUIRE(gbits + cfg->gp_log_leaves >= cfg->log_n, "harness: grand-product point shorter than the opening point");
+        COZK_REQUIRE(cfg->n_fr + cfg->n_u16 + cfg->n_u32 + cfg->n_flags >= 1, "harness: no polynomials");
+        h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
+        h->N = (size_t)1 << cfg->log_n;
+        h->parties.resize(h->nparties);
+        for (int p = 0; p < h->nparties; p++) {
+            PartyState& ps = h->parties[p];
+            ps.party = p;
+            int rc = cozk_ctx_create(cfg->devices[p], &ps.ctx);
+            if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
+            ps.own_ctx = true;
+            HIP_TRY(hipSetDevice(ps.ctx->device));
+            setup_party(h, ps);
+        }
+    } catch (const CozkError& e) {
+        h->error = e.what();
+        *out = h;  // caller reads the error, then destroys
+        return e.code;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        *out = h;
+        return COZK_ERR_INTERNAL;
+    }
+    *out = h;
+    return COZK_OK;
+}
+
+const char* cozk_harness_error(const cozk_harness* h) { return h ? h->error.c_str() : "null harness"; }
+
+int cozk_harness_destroy(cozk_harness* h) {
+    if (!h) return COZK_OK;
+    for (auto& ps : h->parties) {
+        if (ps.ctx) (void)hipSetDevice(ps.ctx->device);
+        ps.polys.clear();
+        ps.commit_vecs.clear();
+        ps.small_polys.clear();
+        ps.small_commit_vecs.clear();
+        ps.leaves = LayerH();
+        ps.setup.reset();
+        if (ps.own_ctx && ps.ctx) cozk_ctx_destroy(ps.ctx);
+    }
+    delete h;
+    return COZK_OK;
+}
+
+// one full pass of the hot path (the bench "step"); verify != 0 also runs the plain verifier
+int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
+    if (!h || !res) return COZK_ERR_INVALID_ARG;
+    memset(res, 0, sizeof *res);
+    res->verified = -1;
+    int np = h->nparties;
+    InProcStar star(np);
+    InProcRing ring(&star.abort);
+    std::vector<std::unique_ptr<InProcStarWorker>> sw;
+    std::vector<std::unique_ptr<InProcRingNet>> rn;
+    for (int p = 0; p < np; p++) {
+        sw.emplace_back(new InProcStarWorker(&star, p));
+        rn.emplace_back(np == 3 ? new InProcRingNet(&ring, p) : nullptr);
+        h->parties[p].error.clear();
+    }
+    std::vector<std::thread> threads;
+    double t0 = now_ms();
+    for (int p = 0; p < np; p++) {
+        threads.emplace_back([&, p] {
+            try {
+                worker_main(h, h->parties[p], sw[p].get(), rn[p].get());
+            } catch (const std::exception& e) {
+                h->parties[p].error = e.what();
+                star.abort.flag.store(true);
+            }
+        });
+    }
+    ProofBundle proof;
+    std::string why;
+    int verified = -1;
+    int rc = COZK_OK;
+    try {
+        InProcStarCoordinator coord(&star);
+        verified = coordinator_main(h, coord, proof, verify != 0, why);
+    } catch (const std::exception& e) {
+        h->error = std::string("coordinator: ") + e.what();
+        star.abort.flag.store(true);
+        rc = COZK_ERR_INTERNAL;
+    }
+    for (auto& t : threads) t.join();
+    double t1 = now_ms();
+    for (int p = 0; p < np; p++) {
+        if (!h->parties[p].error.empty()) {
+            h->error = "party " + std::to_string(p) + ": " + h->parties[p].error;
+            rc = COZK_ERR_INTERNAL;
+        }
+    }
+    if (rc != COZK_OK) return rc;
+    if (verified == 0) h->error = "verification failed: " + why;
+    res->verified = verified;
+    res->wall_ms = t1 - t0;
+    for (int p = 0; p < np; p++) {
+        PartyState& ps = h->parties[p];
+        res->t_commit_ms = std::max(res->t_commit_ms, ps.t_commit);
+        res->t_gp_construct_ms = std::max(res->t_gp_construct_ms, ps.t_construct);
+        res->t_gp_prove_ms = std::max(res->t_gp_prove_ms, ps.t_gp);
+        res->t_eval_ms = std::max(res->t_eval_ms, ps.t_eval);
+        res->t_open_ms = std::max(res->t_open_ms, ps.t_open);
+        res->t_worker_ms = std::max(res->t_worker_ms, ps.t_total);
+        res->bytes_star_up += ps.star_up;
+        res->bytes_star_down += ps.star_down;
+        res->bytes_ring += ps.ring_bytes;
+        res->star_messages += ps.star_msgs;
+    }
+    h->last_proof = proof.serialize();
+    res->proof_len = h->last_proof.size();
+    Sha256 s;
+    s.update(h->last_proof.data(), h->last_proof.size());
+    s.final(res->proof_digest);
+    return COZK_OK;
+}
+
+// serialized proof of the last prove (cozk_harness_result.proof_len bytes)
+int cozk_harness_proof_bytes(const cozk_harness* h, uint8_t* out, size_t cap) {
+    if (!h || !out || cap < h->last_proof.size()) return COZK_ERR_INVALID_ARG;
+    memcpy(out, h->last_proof.data(), h->last_proof.size());
+    return COZK_OK;
+}
+
+// context of party p (profiling hooks: cozk_prof_enable / cozk_prof_read)
+cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party) {
+    if (!h || party < 0 || party >= h->nparties) return nullptr;
+    return h->parties[party].ctx;
+}
+
+}  // extern "C"

@@ -1,0 +1,828 @@
+// Worker-side and coordinator-side drivers of the hot path, written against the network seam
+// (net.hpp) and the C ABI kernels.  One-to-one with the reference's round loops:
+//
+//   prove_sumcheck                    co-jolt/src/subprotocols/sumcheck.rs:96-131
+//   coordinate_prove_arbitrary        co-jolt/src/subprotocols/sumcheck.rs:134-165
+//   Rep3BatchedDenseGrandProduct      co-jolt/src/subprotocols/grand_product.rs:219-282
+//   prove_grand_product_worker        co-jolt/src/subprotocols/grand_product.rs:111-130
+//   prove_layer / coordinate_prove_layer   grand_product.rs:143-217
+//   Rep3ProverOpeningAccumulator      co-jolt/src/poly/opening_proof.rs:63-438
+//   PST13                             co-jolt/src/poly/commitment/pst13.rs
+//
+// `mode` = COZK_MODE_REP3 (three parties, shares {a,b}) or COZK_MODE_PLAIN (one party, the plain
+// prover: same message schedule with a single worker whose additive share is the value itself).
+#pragma once
+#include <memory>
+
+#include "net.hpp"
+
+namespace cozk {
+
+// ---------------------------------------------------------------- RAII handles over the C ABI
+struct VecH {
+    cozk_vec* h = nullptr;
+    VecH() {}
+    explicit VecH(cozk_vec* v) : h(v) {}
+    VecH(const VecH&) = delete;
+    VecH& operator=(const VecH&) = delete;
+    VecH(VecH&& o) noexcept : h(o.h) { o.h = nullptr; }
+    VecH& operator=(VecH&& o) noexcept {
+        if (this != &o) {
+            cozk_vec_free(h);
+            h = o.h;
+            o.h = nullptr;
+        }
+        return *this;
+    }
+    ~VecH() { cozk_vec_free(h); }
+};
+struct PolyH {
+    cozk_poly* h = nullptr;
+    PolyH() {}
+    explicit PolyH(cozk_poly* p) : h(p) {}
+    PolyH(const PolyH&) = delete;
+    PolyH& operator=(const PolyH&) = delete;
+    PolyH(PolyH&& o) noexcept : h(o.h) { o.h = nullptr; }
+    PolyH& operator=(PolyH&& o) noexcept {
+        if (this != &o) {
+            cozk_poly_free(h);
+            h = o.h;
+            o.h = nullptr;
+        }
+        return *this;
+    }
+    ~PolyH() { cozk_poly_free(h); }
+};
+struct LayerH {
+    cozk_layer* h = nullptr;
+    LayerH() {}
+    explicit LayerH(cozk_layer* p) : h(p) {}
+    LayerH(const LayerH&) = delete;
+    LayerH& operator=(const LayerH&) = delete;
+    LayerH(LayerH&& o) noexcept : h(o.h) { o.h = nullptr; }
+    LayerH& operator=(LayerH&& o) noexcept {
+        if (this != &o) {
+            cozk_layer_free(h);
+            h = o.h;
+            o.h = nullptr;
+        }
+        return *this;
+    }
+    ~LayerH() { cozk_layer_free(h); }
+};
+struct EqH {
+    cozk_spliteq* h = nullptr;
+    EqH() {}
+    EqH(const EqH&) = delete;
+    EqH& operator=(const EqH&) = delete;
+    ~EqH() { cozk_spliteq_free(h); }
+};
+
+static inline std::vector<uint64_t> to_abi(const std::vector<fe>& v) {
+    std::vector<uint64_t> o(4 * v.size());
+    for (size_t i = 0; i < v.size(); i++) fe_to_u64x4(v[i], o.data() + 4 * i);
+    return o;
+}
+
+// a Rep3 share (or a plain value with b = 0)
+struct Share {
+    fe a, b;
+};
+
+struct WorkerEnv {
+    cozk_ctx* ctx;
+    int mode;   // COZK_MODE_PLAIN / COZK_MODE_REP3
+    int party;  // PartyID 0..2 (0 for the plain prover)
+    StarNetWorker* star;
+    RingNet* ring;            // null for the plain prover
+    uint64_t seed_self = 0;   // PRF key shared with the next party
+    uint64_t seed_prev = 0;   // PRF key shared with the previous party
+    uint64_t mask_ctr = 0;    // zero-sharing counter (advances identically on all parties)
+
+    // additive::promote_to_trivial_share(value, id) (mpc-core/src/protocols/additive.rs:62-64)
+    fe additive_trivial(const fe& v) const { return party == 0 ? v : Fr::zero(); }
+    // rep3::arithmetic::promote_to_trivial_share(id, value) (types.rs:90-96)
+    Share rep3_trivial(const fe& v) const {
+        Share s{Fr::zero(), Fr::zero()};
+        if (mode == COZK_MODE_PLAIN || party == 0) s.a = v;
+        else if (party == 1) s.b = v;
+        return s;
+    }
+    // Rep3PrimeFieldShare::into_additive (types.rs:76-81); identity for the plain prover
+    fe into_additive(const Share& s) const {
+        if (mode == COZK_MODE_PLAIN) return s.a;
+        return Fr::mul(Fr::add(s.a, s.b), fr_two_inv());
+    }
+};
+
+// ================================================================= cubic sumcheck over one GKR layer
+struct SumcheckResult {
+    std::vector<fe> r;
+    Share left, right;
+};
+
+// Rep3BatchedCubicSumcheckWorker::prove_sumcheck (sumcheck.rs:96-131)
+static SumcheckResult prove_sumcheck(WorkerEnv& env, cozk_layer* layer, const fe& claim, cozk_spliteq* eq, int num_rounds) {
+    SumcheckResult res;
+    fe previous_claim = claim;
+    for (int round = 0; round < num_rounds; round++) {
+        uint64_t pc[4], coeffs[16];
+        fe_to_u64x4(previous_claim, pc);
+        rc_check(cozk_layer_compute_cubic(env.ctx, layer, eq, pc, coeffs), env.ctx, "compute_cubic");
+        Writer w;
+        std::vector<fe> cf(4);
+        for (int i = 0; i < 4; i++) cf[i] = fe_from_u64x4(coeffs + 4 * i);
+        w.vec_fr(cf);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r_j = rd.fr();
+        fe next_claim = rd.fr();
+        res.r.push_back(r_j);
+        uint64_t rr[4];
+        fe_to_u64x4(r_j, rr);
+        rc_check(cozk_layer_bind(env.ctx, layer, rr), env.ctx, "layer_bind");
+        rc_check(cozk_spliteq_bind(env.ctx, eq, rr), env.ctx, "spliteq_bind");
+        previous_claim = env.additive_trivial(next_claim);
+    }
+    uint64_t fc[16];
+    rc_check(cozk_layer_final_claims(env.ctx, layer, fc), env.ctx, "final_claims");
+    res.left = Share{fe_from_u64x4(fc), fe_from_u64x4(fc + 4)};
+    res.right = Share{fe_from_u64x4(fc + 8), fe_from_u64x4(fc + 12)};
+    Writer w;
+    w.fr(res.left.a);
+    w.fr(res.left.b);
+    w.fr(res.right.a);
+    w.fr(res.right.b);
+    env.star->send_response(w.b);
+    return res;
+}
+
+struct SumcheckProof {
+    std::vector<std::vector<fe>> compressed_polys;
+};
+
+// coordinate_prove_arbitrary (sumcheck.rs:134-165)
+static std::vector<fe> coordinate_prove_arbitrary(StarNetCoordinator& net, Transcript& tr, int num_rounds, SumcheckProof& proof) {
+    std::vector<fe> r;
+    for (int round = 0; round < num_rounds; round++) {
+        std::vector<std::vector<fe>> parts;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            parts.push_back(rd.vec_fr());
+        }
+        std::vector<fe> poly = combine_additive(parts);
+        std::vector<fe> comp = unipoly_compress(poly);
+        tr.append_scalars(comp);
+        fe r_j = tr.challenge_scalar();
+        r.push_back(r_j);
+        fe claim = unipoly_eval(poly, r_j);
+        Writer w;
+        w.fr(r_j);
+        w.fr(claim);
+        net.broadcast_request(w.b);
+        proof.compressed_polys.push_back(comp);
+    }
+    return r;
+}
+
+// receive_final_claims (sumcheck.rs:53-75): combine_field_element = a0 + a1 + a2
+static void receive_final_claims(StarNetCoordinator& net, fe& left, fe& right) {
+    left = Fr::zero();
+    right = Fr::zero();
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        fe la = rd.fr();
+        (void)rd.fr();
+        fe ra = rd.fr();
+        (void)rd.fr();
+        left = Fr::add(left, la);
+        right = Fr::add(right, ra);
+    }
+}
+
+// ================================================================= dense batched grand product (GKR)
+struct GrandProductLayerProof {
+    SumcheckProof proof;
+    fe left_claim, right_claim;
+};
+struct GrandProductProof {
+    std::vector<fe> outputs;
+    std::vector<GrandProductLayerProof> gkr_layers;
+};
+
+struct Rep3BatchedDenseGrandProduct {
+    std::vector<LayerH> layers;  // layers[0] = leaves ... layers.back() = top
+
+    // construct (grand_product.rs:239-255): layer[i+1] = mul_vec(L(layer[i]), R(layer[i]))
+    static Rep3BatchedDenseGrandProduct construct(WorkerEnv& env, LayerH leaves, size_t batch_size) {
+        size_t n = cozk_layer_len(leaves.h);
+        COZK_REQUIRE(batch_size > 0 && n % batch_size == 0, "grand product: leaves.len() % batch_size != 0");
+        size_t per = n / batch_size;
+        COZK_REQUIRE(per >= 2 && (per & (per - 1)) == 0, "grand product: leaves per circuit must be a power of two >= 2");
+        int num_layers = 0;
+        while (((size_t)1 << num_layers) < per) num_layers++;
+        Rep3BatchedDenseGrandProduct gp;
+        gp.layers.push_back(std::move(leaves));
+        for (int i = 0; i < num_layers - 1; i++) {
+            cozk_layer* prev = gp.layers[i].h;
+            size_t n_out = (cozk_layer_len(prev) + 1) / 2;
+            cozk_vec* ca = nullptr;
+            rc_check(cozk_layer_output_local(env.ctx, prev, env.mode == COZK_MODE_REP3 ? 1 : 0, env.seed_self, env.seed_prev,
+                                             env.mask_ctr, &ca),
+                     env.ctx, "layer_output_local");
+            VecH va(ca);
+            env.mask_ctr += n_out;
+            cozk_layer* nl = nullptr;
+            if (env.mode == COZK_MODE_REP3) {
+                cozk_vec* cb = nullptr;
+                rc_check(cozk_vec_alloc(env.ctx, n_out, COZK_SCALAR_FR, &cb), env.ctx, "vec_alloc");
+                VecH vb(cb);
+                // ring reshare: own c.a -> next, c.b <- prev (arithmetic.rs:148-150)
+                env.ring->reshare(env.ctx, (const fe*)cozk_vec_device_ptr(va.h), (fe*)cozk_vec_device_ptr(vb.h), n_out);
+                rc_check(cozk_layer_create(env.ctx, COZK_MODE_REP3, va.h, vb.h, 1, &nl), env.ctx, "layer_create");
+            } else {
+                rc_check(cozk_layer_create(env.ctx, COZK_MODE_PLAIN, va.h, nullptr, 1, &nl), env.ctx, "layer_create");
+            }
+            gp.layers.push_back(LayerH(nl));
+        }
+        return gp;
+    }
+
+    size_t num_layers() const { return layers.size(); }
+
+    // claimed_outputs (grand_product.rs:266-272)
+    std::vector<fe> claimed_outputs(WorkerEnv& env) {
+        cozk_layer* top = layers.back().h;
+        size_t n = cozk_layer_len(top) / 2;
+        std::vector<uint64_t> out(4 * n);
+        rc_check(cozk_layer_claimed_outputs(env.ctx, top, out.data()), env.ctx, "claimed_outputs");
+        std::vector<fe> v(n);
+        for (size_t i = 0; i < n; i++) v[i] = fe_from_u64x4(out.data() + 4 * i);
+        return v;
+    }
+
+    // prove_layer (grand_product.rs:186-217)
+    static void prove_layer(WorkerEnv& env, cozk_layer* layer, fe& claim, std::vector<fe>& r_grand_product) {
+        EqH eq;
+        std::vector<uint64_t> w = to_abi(r_grand_product);
+        rc_check(cozk_spliteq_new(env.ctx, w.data(), (int)r_grand_product.size(), &eq.h), env.ctx, "spliteq_new");
+        int num_rounds = (int)r_grand_product.size();
+        if (env.party == 0) {
+            Writer wr;
+            wr.u64((uint64_t)num_rounds);
+            env.star->send_response(wr.b);
+        }
+        SumcheckResult sc = prove_sumcheck(env, layer, claim, eq.h, num_rounds);
+        r_grand_product.assign(sc.r.rbegin(), sc.r.rend());
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r_layer = rd.fr();
+        // claim = add_mul_public(left, right - left, r_layer).into_additive()
+        Share s;
+        s.a = Fr::add(sc.left.a, Fr::mul(Fr::sub(sc.right.a, sc.left.a), r_layer));
+        s.b = Fr::add(sc.left.b, Fr::mul(Fr::sub(sc.right.b, sc.left.b), r_layer));
+        claim = env.into_additive(s);
+        r_grand_product.push_back(r_layer);
+    }
+
+    // prove_grand_product_worker (grand_product.rs:111-130).  Layers are bound destructively.
+    std::vector<fe> prove_grand_product_worker(WorkerEnv& env) {
+        std::vector<fe> outputs = claimed_outputs(env);
+        Writer w;
+        w.vec_fr(outputs);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        std::vector<fe> r = rd.vec_fr();
+        fe claim = env.additive_trivial(rd.fr());
+        for (size_t i = layers.size(); i-- > 0;) prove_layer(env, layers[i].h, claim, r);
+        return r;
+    }
+};
+
+// coordinate_prove_layer (grand_product.rs:143-183)
+static GrandProductLayerProof coordinate_prove_layer(StarNetCoordinator& net, Transcript& tr, fe& claim, std::vector<fe>& r_grand_product) {
+    GrandProductLayerProof lp;
+    Bytes nb = net.receive_response(0);
+    Reader rd(nb);
+    int num_rounds = (int)rd.u64();
+    std::vector<fe> r_sumcheck = coordinate_prove_arbitrary(net, tr, num_rounds, lp.proof);
+    receive_final_claims(net, lp.left_claim, lp.right_claim);
+    tr.append_scalar(lp.left_claim);
+    tr.append_scalar(lp.right_claim);
+    r_grand_product.assign(r_sumcheck.rbegin(), r_sumcheck.rend());
+    fe r_layer = tr.challenge_scalar();
+    Writer w;
+    w.fr(r_layer);
+    net.broadcast_request(w.b);
+    claim = Fr::add(lp.left_claim, Fr::mul(r_layer, Fr::sub(lp.right_claim, lp.left_claim)));
+    r_grand_product.push_back(r_layer);
+    return lp;
+}
+
+// cooridinate_prove_grand_product (grand_product.rs:56-85) -> proof, final (claim, r)
+static GrandProductProof coordinate_prove_grand_product(StarNetCoordinator& net, Transcript& tr, size_t num_layers, fe& claim_out,
+                                                        std::vector<fe>& r_out) {
+    GrandProductProof proof;
+    std::vector<std::vector<fe>> parts;
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        parts.push_back(rd.vec_fr());
+    }
+    proof.outputs = combine_additive(parts);
+    tr.append_scalars(proof.outputs);
+    // DensePolynomial::new_padded(outputs).evaluate(r)
+    std::vector<fe> padded = proof.outputs;
+    while (padded.size() & (padded.size() - 1)) padded.push_back(Fr::zero());
+    int nv = 0;
+    while (((size_t)1 << nv) < padded.size()) nv++;
+    std::vector<fe> r = tr.challenge_vector(nv);
+    std::vector<fe> eq = eq_evals_host(r);
+    fe claim = Fr::zero();
+    for (size_t i = 0; i < padded.size(); i++) claim = Fr::add(claim, Fr::mul(eq[i], padded[i]));
+    Writer w;
+    w.vec_fr(r);
+    w.fr(claim);
+    net.broadcast_request(w.b);
+    for (size_t i = 0; i < num_layers; i++) proof.gkr_layers.push_back(coordinate_prove_layer(net, tr, claim, r));
+    claim_out = claim;
+    r_out = r;
+    return proof;
+}
+
+// plain verifier of the GKR proof (replays the transcript; checks g(0)+g(1) = claim implicitly via
+// decompression and the layer reduction eq(r, r') L R = g(r')).  Returns false on any mismatch.
+static bool verify_grand_product(const GrandProductProof& proof, Transcript& tr, fe& claim_out, std::vector<fe>& r_out) {
+    tr.append_scalars(proof.outputs);
+    std::vector<fe> padded = proof.outputs;
+    while (padded.size() & (padded.size() - 1)) padded.push_back(Fr::zero());
+    int nv = 0;
+    while (((size_t)1 << nv) < padded.size()) nv++;
+    std::vector<fe> r = tr.challenge_vector(nv);
+    std::vector<fe> eqv = eq_evals_host(r);
+    fe claim = Fr::zero();
+    for (size_t i = 0; i < padded.size(); i++) claim = Fr::add(claim, Fr::mul(eqv[i], padded[i]));
+    fe one = Fr::one();
+    for (const GrandProductLayerProof& lp : proof.gkr_layers) {
+        std::vector<fe> rs;
+        fe e = claim;
+        for (const auto& comp : lp.proof.compressed_polys) {
+            std::vector<fe> poly = unipoly_decompress(comp, e);
+            tr.append_scalars(comp);
+            fe r_j = tr.challenge_scalar();
+            rs.push_back(r_j);
+            e = unipoly_eval(poly, r_j);
+        }
+        if (rs.size() != r.size()) return false;
+        fe eq = one;
+        for (size_t i = 0; i < r.size(); i++) {
+            const fe& a = r[i];
+            const fe& b = rs[rs.size() - 1 - i];
+            fe ab = Fr::mul(a, b);
+            // a b + (1-a)(1-b) = 1 - a - b + 2ab
+            fe t = Fr::add(Fr::sub(Fr::sub(one, a), b), Fr::dbl(ab));
+            eq = Fr::mul(eq, t);
+        }
+        if (!Fr::eq(Fr::mul(Fr::mul(eq, lp.left_claim), lp.right_claim), e)) return false;
+        tr.append_scalar(lp.left_claim);
+        tr.append_scalar(lp.right_claim);
+        r.assign(rs.rbegin(), rs.rend());
+        fe r_layer = tr.challenge_scalar();
+        claim = Fr::add(lp.left_claim, Fr::mul(r_layer, Fr::sub(lp.right_claim, lp.left_claim)));
+        r.push_back(r_layer);
+    }
+    claim_out = claim;
+    r_out = r;
+    return true;
+}
+
+// ================================================================= PST13
+struct PST13Commitment {
+    uint64_t nv;
+    g1_affine g_product;
+};
+
+// SRS levels `ck.powers_of_g[i]` (size 2^(nv-i)) live concatenated in one device handle; `halves`
+// holds G[2b] + G[2b+1] of the same array, i.e. the level-i bases for the duplicated scalars
+// q[x >> 1] of `open` (pst13.rs:459) at offset level_offset(i) / 2.
+struct PST13Setup {
+    int nv = 0;
+    cozk_bases* powers_all = nullptr;  // levels 0..nv-1 concatenated: N, N/2, ..., 2  (2N - 2 points)
+    cozk_bases* halves = nullptr;      // pair sums of powers_all (N - 1 points)
+    g1_affine g;                       // generator
+    std::vector<fe> trapdoor;          // t (harness / tests only: pairing-free `check`)
+    size_t level_offset(int i) const { return ((size_t)1 << (nv + 1)) - ((size_t)1 << (nv - i + 1)); }
+    ~PST13Setup() {
+        cozk_bases_free(powers_all);
+        cozk_bases_free(halves);
+    }
+};
+
+static inline g1_affine abi_to_g1(const uint64_t* xy, int inf) {
+    g1_affine a;
+    a.x = fe_from_u64x4(xy);
+    a.y = fe_from_u64x4(xy + 4);
+    if (inf) {
+        a.x = Fq::zero();
+        a.y = Fq::zero();
+    }
+    return a;
+}
+
+struct PST13 {
+    // MultilinearPC::setup(nv, rng) with the trapdoor t supplied (PST13::setup, pst13.rs:49-62).
+    // powers_of_g[i][b] = g^{eq_le(t[i..], b)}: index bit j of b pairs with t[i + j].
+    static std::unique_ptr<PST13Setup> setup(cozk_ctx* ctx, const std::vector<fe>& t, int precompute = 1) {
+        std::unique_ptr<PST13Setup> s(new PST13Setup());
+        int nv = (int)t.size();
+        COZK_REQUIRE(nv >= 1 && nv <= 26, "PST13::setup: nv out of range");
+        s->nv = nv;
+        s->trapdoor = t;
+        s->g.x = Fq::one();
+        s->g.y = Fq::from_u64(2);
+        size_t total = ((size_t)1 << (nv + 1)) - 2;
+        cozk_vec* sc = nullptr;
+        rc_check(cozk_vec_alloc(ctx, total, COZK_SCALAR_FR, &sc), ctx, "vec_alloc");
+        VecH scv(sc);
+        // level i table = evals_be(reverse(t[i..])), built on device straight into its slice
+        for (int i = 0; i < nv; i++) {
+            std::vector<fe> rev(t.rbegin(), t.rend() - i);
+            std::vector<uint64_t> w = to_abi(rev);
+            cozk_vec* ev = nullptr;
+            rc_check(cozk_eq_evals(ctx, w.data(), nv - i, &ev), ctx, "eq_evals");
+            VecH evh(ev);
+            HIP_TRY(hipMemcpyAsync((fe*)cozk_vec_device_ptr(scv.h) + s->level_offset(i), cozk_vec_device_ptr(evh.h),
+                                   ((size_t)1 << (nv - i)) * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+        uint64_t gxy[8];
+        fe_to_u64x4(s->g.x, gxy);
+        fe_to_u64x4(s->g.y, gxy + 4);
+        rc_check(cozk_bases_from_scalars(ctx, scv.h, gxy, precompute, &s->powers_all), ctx, "bases_from_scalars");
+        rc_check(cozk_bases_pair_sums(ctx, s->powers_all, precompute, &s->halves), ctx, "bases_pair_sums");
+        return s;
+    }
+
+    // batch_commit (pst13.rs:299-331): one MSM per polynomial over powers_of_g[0][..len]
+    static std::vector<PST13Commitment> batch_commit(cozk_ctx* ctx, const PST13Setup& s, const std::vector<cozk_vec*>& polys) {
+        size_t k = polys.size();
+        std::vector<PST13Commitment> out(k);
+        if (k == 0) return out;
+        std::vector<uint64_t> xy(8 * k);
+        std::vector<int> inf(k);
+        std::vector<size_t> offs(k, 0);
+        rc_check(cozk_batch_msm_slices(ctx, s.powers_all, offs.data(), polys.data(), nullptr, k, xy.data(), inf.data()), ctx, "batch_msm");
+        for (size_t i = 0; i < k; i++) {
+            size_t len = cozk_vec_len(polys[i]);
+            uint64_t nv = 0;
+            while (((size_t)1 << nv) < len) nv++;
+            out[i].nv = nv;
+            out[i].g_product = abi_to_g1(xy.data() + 8 * i, inf[i]);
+        }
+        return out;
+    }
+
+    // `open` (pst13.rs:428-474) on the share-a evaluations; point already reversed by the caller.
+    // All nv MSMs go out as one launch set over `halves`.
+    static std::vector<g1_affine> open(cozk_ctx* ctx, const PST13Setup& s, const cozk_vec* evals, const std::vector<fe>& point) {
+        int nv = s.nv;
+        COZK_REQUIRE(cozk_vec_len(evals) == ((size_t)1 << nv), "PST13::open: invalid size of polynomial");
+        COZK_REQUIRE((int)point.size() == nv, "PST13::open: point length");
+        std::vector<VecH> q(nv), r(nv);
+        const cozk_vec* cur = evals;
+        for (int i = 0; i < nv; i++) {
+            size_t half = (size_t)1 << (nv - i - 1);
+            cozk_vec *qv = nullptr, *rv = nullptr;
+            rc_check(cozk_vec_alloc(ctx, half, COZK_SCALAR_FR, &qv), ctx, "vec_alloc");
+            q[i] = VecH(qv);
+            rc_check(cozk_vec_alloc(ctx, half, COZK_SCALAR_FR, &rv), ctx, "vec_alloc");
+            r[i] = VecH(rv);
+            uint64_t p[4];
+            fe_to_u64x4(point[i], p);
+            // the fold reads `cur` (len 2*half): for i > 0 that is r[i-1]
+            cozk_vec view = *cur;
+            view.n = 2 * half;
+            rc_check(cozk_pst_fold(ctx, &view, p, q[i].h, r[i].h), ctx, "pst_fold");
+            cur = r[i].h;
+        }
+        std::vector<const cozk_vec*> qs(nv);
+        std::vector<size_t> offs(nv);
+        for (int i = 0; i < nv; i++) {
+            qs[i] = q[i].h;
+            offs[i] = s.level_offset(i) / 2;
+        }
+        std::vector<uint64_t> xy(8 * nv);
+        std::vector<int> inf(nv);
+        rc_check(cozk_batch_msm_slices(ctx, s.halves, offs.data(), qs.data(), nullptr, nv, xy.data(), inf.data()), ctx, "open msm");
+        std::vector<g1_affine> proofs(nv);
+        for (int i = 0; i < nv; i++) proofs[i] = abi_to_g1(xy.data() + 8 * i, inf[i]);
+        return proofs;
+    }
+
+    // prove_rep3 (pst13.rs:125-137): open share-a at the reversed point, send the proof points
+    static void prove_rep3(WorkerEnv& env, const PST13Setup& s, cozk_poly* joint, const std::vector<fe>& opening_point) {
+        std::vector<fe> rev(opening_point.rbegin(), opening_point.rend());
+        cozk_vec* av = nullptr;
+        rc_check(cozk_poly_share_view(env.ctx, joint, 0, &av), env.ctx, "share_view");
+        VecH a(av);
+        std::vector<g1_affine> pf = open(env.ctx, s, a.h, rev);
+        Writer w;
+        w.vec_g1(pf);
+        env.star->send_response(w.b);
+    }
+
+    // coordinate_prove (pst13.rs:110-122): point-wise sum of the parties' proofs
+    static std::vector<g1_affine> coordinate_prove(StarNetCoordinator& net) {
+        std::vector<g1_xyzz> acc;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            std::vector<g1_affine> pf = rd.vec_g1();
+            if (acc.empty()) acc.assign(pf.size(), G1::identity());
+            if (acc.size() != pf.size()) throw CozkError(COZK_ERR_INTERNAL, "coordinate_prove: proof length mismatch");
+            for (size_t i = 0; i < pf.size(); i++) acc[i] = G1::add_mixed(acc[i], pf[i]);
+        }
+        std::vector<g1_affine> out(acc.size());
+        for (size_t i = 0; i < acc.size(); i++) out[i] = G1::to_affine(acc[i]);
+        return out;
+    }
+
+    // combine_commitment_shares (pst13.rs:72-108): sum of the parties' share commitments
+    static PST13Commitment combine_commitment_shares(const std::vector<PST13Commitment>& shares) {
+        g1_xyzz acc = G1::identity();
+        for (const auto& c : shares) {
+            if (c.nv != shares[0].nv) throw CozkError(COZK_ERR_INTERNAL, "combine_commitment_shares: nv mismatch");
+            acc = G1::add_mixed(acc, c.g_product);
+        }
+        return PST13Commitment{shares[0].nv, G1::to_affine(acc)};
+    }
+
+    static g1_xyzz scalar_mul(const g1_affine& p, const fe& s_mont) {
+        fe sc = Fr::from_mont(s_mont);
+        g1_xyzz acc = G1::identity();
+        for (int k = 7; k >= 0; k--)
+            for (int b = 31; b >= 0; b--) {
+                acc = G1::dbl(acc);
+                if ((sc.l[k] >> b) & 1u) acc = G1::add_mixed(acc, p);
+            }
+        return acc;
+    }
+
+    // combine_commitments (pst13.rs:333-348): sum_i coeff_i * C_i
+    static g1_affine combine_commitments(const std::vector<g1_affine>& cs, const std::vector<fe>& coeffs) {
+        g1_xyzz acc = G1::identity();
+        for (size_t i = 0; i < cs.size(); i++) acc = G1::add(acc, scalar_mul(cs[i], coeffs[i]));
+        return G1::to_affine(acc);
+    }
+
+    // pairing-free restatement of MultilinearPC::check with the trapdoor known (verify, pst13.rs:367-385):
+    // C - v g == sum_i (t_i - p_i) pi_i, point in PST (reversed) order
+    static bool check_with_trapdoor(const PST13Setup& s, const g1_affine& commitment, const std::vector<fe>& point_rev, const fe& value,
+                                    const std::vector<g1_affine>& proofs) {
+        if ((int)proofs.size() != s.nv || (int)point_rev.size() != s.nv) return false;
+        g1_xyzz lhs = G1::add_mixed(G1::neg(scalar_mul(s.g, value)), commitment);
+        g1_xyzz rhs = G1::identity();
+        for (int i = 0; i < s.nv; i++) rhs = G1::add(rhs, scalar_mul(proofs[i], Fr::sub(s.trapdoor[i], point_rev[i])));
+        g1_affine l = G1::to_affine(lhs), r = G1::to_affine(rhs);
+        return Fq::eq(l.x, r.x) && Fq::eq(l.y, r.y);
+    }
+};
+
+// ================================================================= opening accumulator
+struct Rep3ProverOpening {
+    PolyH polynomial;  // RLC of the polynomials opened at one point
+    PolyH eq_poly;     // EQ(x, opening_point) as a plain polynomial
+    std::vector<fe> opening_point;
+    Share claim;
+    size_t num_vars;
+};
+
+struct ReducedOpeningProof {
+    SumcheckProof sumcheck_proof;
+    std::vector<fe> sumcheck_claims;
+    std::vector<g1_affine> joint_opening_proof;
+};
+
+struct Rep3ProverOpeningAccumulator {
+    std::vector<Rep3ProverOpening> openings;
+
+    // append (opening_proof.rs:77-106)
+    void append(WorkerEnv& env, const std::vector<cozk_poly*>& polynomials, const cozk_vec* eq_evals, const std::vector<fe>& opening_point,
+                const std::vector<fe>& claims) {
+        COZK_REQUIRE(polynomials.size() == claims.size() && !polynomials.empty(), "append: polynomials / claims mismatch");
+        Writer w;
+        w.vec_fr(claims);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe rho = rd.fr();
+        fe batched_claim = rd.fr();
+        std::vector<fe> rho_powers(1, Fr::one());
+        for (size_t i = 1; i < polynomials.size(); i++) rho_powers.push_back(Fr::mul(rho_powers[i - 1], rho));
+        std::vector<uint64_t> cf = to_abi(rho_powers);
+        cozk_poly* batched = nullptr;
+        rc_check(cozk_poly_linear_combination(env.ctx, polynomials.data(), cf.data(), polynomials.size(), env.mode, env.party, &batched),
+                 env.ctx, "linear_combination");
+        Rep3ProverOpening op;
+        op.polynomial = PolyH(batched);
+        cozk_poly* eqp = nullptr;
+        rc_check(cozk_poly_create(env.ctx, COZK_MODE_PLAIN, eq_evals, nullptr, &eqp), env.ctx, "poly_create(eq)");
+        op.eq_poly = PolyH(eqp);
+        op.opening_point = opening_point;
+        op.claim = env.rep3_trivial(batched_claim);
+        op.num_vars = opening_point.size();
+        openings.push_back(std::move(op));
+    }
+
+    // receive_claims (opening_proof.rs:108-128), coordinator side
+    static std::vector<fe> receive_claims(StarNetCoordinator& net, Transcript& tr) {
+        std::vector<std::vector<fe>> parts;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            parts.push_back(rd.vec_fr());
+        }
+        std::vector<fe> claims = combine_additive(parts);
+        fe rho = tr.challenge_scalar();
+        fe pw = Fr::one(), batched = Fr::zero();
+        for (size_t i = 0; i < claims.size(); i++) {
+            batched = Fr::add(batched, Fr::mul(pw, claims[i]));
+            pw = Fr::mul(pw, rho);
+        }
+        Writer w;
+        w.fr(rho);
+        w.fr(batched);
+        net.broadcast_request(w.b);
+        return claims;
+    }
+
+    // compute_quadratic (opening_proof.rs:364-437) -> 3 coefficients
+    std::vector<fe> compute_quadratic(WorkerEnv& env, const std::vector<fe>& coeffs, size_t remaining_rounds, const fe& previous_claim) {
+        size_t k = openings.size();
+        std::vector<fe> e0(k), e2(k);
+        std::vector<const cozk_poly*> lp, le;
+        std::vector<size_t> live;
+        for (size_t i = 0; i < k; i++) {
+            if (remaining_rounds <= openings[i].opening_point.size()) {
+                live.push_back(i);
+                lp.push_back(openings[i].polynomial.h);
+                le.push_back(openings[i].eq_poly.h);
+            } else {
+                size_t rem = remaining_rounds - openings[i].opening_point.size() - 1;
+                fe sc = Fr::mul(env.into_additive(openings[i].claim), fr_from_u64((uint64_t)1 << rem));
+                e0[i] = sc;
+                e2[i] = sc;
+            }
+        }
+        if (!live.empty()) {
+            std::vector<uint64_t> out(8 * live.size());
+            rc_check(cozk_open_quadratic_evals(env.ctx, lp.data(), le.data(), live.size(), out.data()), env.ctx, "open_quadratic");
+            for (size_t j = 0; j < live.size(); j++) {
+                e0[live[j]] = fe_from_u64x4(out.data() + 8 * j);
+                e2[live[j]] = fe_from_u64x4(out.data() + 8 * j + 4);
+            }
+        }
+        fe c0 = Fr::zero(), c2 = Fr::zero();
+        for (size_t i = 0; i < k; i++) {
+            c0 = Fr::add(c0, Fr::mul(e0[i], coeffs[i]));
+            c2 = Fr::add(c2, Fr::mul(e2[i], coeffs[i]));
+        }
+        fe ev[3] = {c0, Fr::sub(previous_claim, c0), c2};
+        std::vector<fe> cf(3);
+        unipoly_from_evals(ev, 3, cf.data());
+        return cf;
+    }
+
+    // prove_batch_opening_reduction (opening_proof.rs:293-361)
+    std::vector<fe> prove_batch_opening_reduction(WorkerEnv& env, const std::vector<fe>& coeffs, std::vector<fe>& claims_out) {
+        size_t max_num_vars = 0;
+        for (auto& o : openings) max_num_vars = std::max(max_num_vars, o.num_vars);
+        if (env.party == 0) {
+            Writer w;
+            w.u64(max_num_vars);
+            env.star->send_response(w.b);
+        }
+        fe e = Fr::zero();
+        for (size_t i = 0; i < openings.size(); i++) {
+            Share cl = openings[i].claim;
+            if (openings[i].num_vars != max_num_vars) {
+                fe sc = fr_from_u64((uint64_t)1 << (max_num_vars - openings[i].num_vars));
+                cl.a = Fr::mul(cl.a, sc);
+                cl.b = Fr::mul(cl.b, sc);
+            }
+            e = Fr::add(e, Fr::mul(env.into_additive(cl), coeffs[i]));
+        }
+        std::vector<fe> r;
+        for (size_t round = 0; round < max_num_vars; round++) {
+            size_t remaining = max_num_vars - round;
+            std::vector<fe> uni = compute_quadratic(env, coeffs, remaining, e);
+            Writer w;
+            w.vec_fr(uni);
+            env.star->send_response(w.b);
+            Bytes req = env.star->receive_request();
+            Reader rd(req);
+            fe r_j = rd.fr();
+            fe new_claim = rd.fr();
+            r.push_back(r_j);
+            e = env.additive_trivial(new_claim);
+            uint64_t rr[4];
+            fe_to_u64x4(r_j, rr);
+            for (auto& o : openings) {
+                if (remaining <= o.opening_point.size()) {
+                    rc_check(cozk_poly_bind(env.ctx, o.eq_poly.h, rr, COZK_HIGH_TO_LOW), env.ctx, "bind eq");
+                    rc_check(cozk_poly_bind(env.ctx, o.polynomial.h, rr, COZK_HIGH_TO_LOW), env.ctx, "bind poly");
+                }
+            }
+        }
+        claims_out.clear();
+        for (auto& o : openings) {
+            uint64_t a[4], b[4] = {0, 0, 0, 0};
+            rc_check(cozk_poly_get_coeff(env.ctx, o.polynomial.h, 0, a, b), env.ctx, "get_coeff");
+            Share s{fe_from_u64x4(a), fe_from_u64x4(b)};
+            claims_out.push_back(env.into_additive(s));
+        }
+        return r;
+    }
+
+    // reduce_and_prove_worker (opening_proof.rs:238-291)
+    void reduce_and_prove_worker(WorkerEnv& env, const PST13Setup& pcs_setup) {
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe rho = rd.fr();
+        std::vector<fe> rho_powers(1, Fr::one());
+        for (size_t i = 1; i < openings.size(); i++) rho_powers.push_back(Fr::mul(rho_powers[i - 1], rho));
+        // "unbound_polys": binds never touch a polynomial's original coefficients on the device, so a
+        // zero-copy chunk view taken before the sumcheck stands in for the reference's clones
+        std::vector<PolyH> unbound;
+        for (auto& o : openings) {
+            cozk_poly* v = nullptr;
+            rc_check(cozk_poly_chunk(env.ctx, o.polynomial.h, 0, cozk_poly_len(o.polynomial.h), &v), env.ctx, "poly_chunk");
+            unbound.push_back(PolyH(v));
+        }
+        std::vector<fe> sumcheck_claims;
+        std::vector<fe> r_sumcheck = prove_batch_opening_reduction(env, rho_powers, sumcheck_claims);
+        Writer w;
+        w.vec_fr(sumcheck_claims);
+        env.star->send_response(w.b);
+        Bytes greq = env.star->receive_request();
+        Reader grd(greq);
+        fe gamma = grd.fr();
+        std::vector<fe> gamma_powers(1, Fr::one());
+        for (size_t i = 1; i < openings.size(); i++) gamma_powers.push_back(Fr::mul(gamma_powers[i - 1], gamma));
+        std::vector<const cozk_poly*> up;
+        for (auto& u : unbound) up.push_back(u.h);
+        std::vector<uint64_t> cf = to_abi(gamma_powers);
+        cozk_poly* joint = nullptr;
+        rc_check(cozk_poly_linear_combination(env.ctx, up.data(), cf.data(), up.size(), env.mode, env.party, &joint), env.ctx, "joint poly");
+        PolyH jp(joint);
+        PST13::prove_rep3(env, pcs_setup, jp.h, r_sumcheck);
+    }
+
+    // reduce_and_prove (opening_proof.rs:181-235), coordinator side
+    static ReducedOpeningProof reduce_and_prove(StarNetCoordinator& net, Transcript& tr, std::vector<fe>& r_out, fe& rho_out, fe& gamma_out) {
+        ReducedOpeningProof proof;
+        fe rho = tr.challenge_scalar();
+        Writer w;
+        w.fr(rho);
+        net.broadcast_request(w.b);
+        Bytes mb = net.receive_response(0);
+        Reader mr(mb);
+        size_t max_num_vars = (size_t)mr.u64();
+        std::vector<fe> r;
+        for (size_t round = 0; round < max_num_vars; round++) {
+            std::vector<std::vector<fe>> parts;
+            for (Bytes& b : net.receive_responses()) {
+                Reader rd(b);
+                parts.push_back(rd.vec_fr());
+            }
+            std::vector<fe> uni = combine_additive(parts);
+            std::vector<fe> comp = unipoly_compress(uni);
+            tr.append_scalars(comp);
+            fe r_j = tr.challenge_scalar();
+            r.push_back(r_j);
+            fe new_claim = unipoly_eval(uni, r_j);
+            Writer ww;
+            ww.fr(r_j);
+            ww.fr(new_claim);
+            net.broadcast_request(ww.b);
+            proof.sumcheck_proof.compressed_polys.push_back(comp);
+        }
+        std::vector<std::vector<fe>> parts;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            parts.push_back(rd.vec_fr());
+        }
+        proof.sumcheck_claims = combine_additive(parts);
+        tr.append_scalars(proof.sumcheck_claims);
+        fe gamma = tr.challenge_scalar();
+        Writer gw;
+        gw.fr(gamma);
+        net.broadcast_request(gw.b);
+        proof.joint_opening_proof = PST13::coordinate_prove(net);
+        r_out = r;
+        rho_out = rho;
+        gamma_out = gamma;
+        return proof;
+    }
+};
+
+}  // namespace cozk

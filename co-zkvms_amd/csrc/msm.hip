@@ -376,27 +376,28 @@ static void launch_scatter(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* cu
         default: throw CozkError(COZK_ERR_INVALID_ARG, "unknown scalar kind");    \
     }
 
-// P MSMs over bases[offset .. offset+n); scalars[p] device pointers of kinds[p]; results -> d_out[P]
-void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_t n, const void* const* scalars,
-                    const int* kinds, size_t P, g1_affine* d_out) {
-    COZK_REQUIRE(offset + n <= bases->n, "msm: base slice out of range");
+// P MSMs: polynomial p runs over bases[offsets[p] .. offsets[p]+ns[p]); scalars[p] = device pointer of
+// kinds[p]; results -> d_out[P]
+void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, const size_t* ns,
+                    const void* const* scalars, const int* kinds, size_t P, g1_affine* d_out) {
     COZK_REQUIRE(P >= 1, "msm: empty batch");
     COZK_REQUIRE((uint64_t)bases->n * (uint64_t)bases->nwin < (1ull << 31), "msm: table too large for 31-bit refs");
     MsmWorkspace& ws = ctx->msm_ws;
     hipStream_t st = ctx->stream;
-    if (n == 0) {
-        HIP_TRY(hipMemsetAsync(d_out, 0, P * sizeof(g1_affine), st));
-        return;
-    }
     const bool pre = bases->nwin == 16;
     const uint32_t G = pre ? 1u : 16u;
     const uint32_t ngroups = (uint32_t)P * G;
     const uint32_t nb = ngroups * NB;
     uint64_t M = 0, bound = 0;
     for (size_t p = 0; p < P; p++) {
-        uint64_t m = (uint64_t)n * kind_nwin(kinds[p]);
+        COZK_REQUIRE(offsets[p] + ns[p] <= bases->n, "msm: base slice out of range");
+        uint64_t m = (uint64_t)ns[p] * kind_nwin(kinds[p]);
         M += m;
         if (m > bound) bound = m;
+    }
+    if (M == 0) {
+        HIP_TRY(hipMemsetAsync(d_out, 0, P * sizeof(g1_affine), st));
+        return;
     }
     COZK_REQUIRE(M < (1ull << 32), "msm: batch too large (reference count exceeds 32 bits)");
     // segment length of level 0: aim at >= ~2^18 lanes, clamp to [8, 64]
@@ -424,14 +425,14 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 1) * 4, st));
     for (size_t p = 0; p < P; p++) {
         uint32_t* h = hist + (size_t)p * G * NB;
-        KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], n, h, pre ? 0 : 1));
+        if (ns[p]) KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], ns[p], h, pre ? 0 : 1));
     }
     // hist doubles as the scatter cursor after the scan
     k_scan<false><<<1, 1024, 0, st>>>(hist, nb, 1, off0, hist);
     for (size_t p = 0; p < P; p++) {
         uint32_t* cur = hist + (size_t)p * G * NB;
-        KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], n, cur, refs, pre ? 0 : 1, (uint32_t)bases->n,
-                                                  (uint32_t)offset));
+        if (ns[p]) KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], ns[p], cur, refs, pre ? 0 : 1, (uint32_t)bases->n,
+                                                           (uint32_t)offsets[p]));
     }
     // level 0
     uint32_t* offA = ws.offA.as<uint32_t>();
@@ -473,15 +474,6 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_
     HIP_TRY(hipGetLastError());
 }
 
-// maximum polynomials per launch set: keeps refs (4 B x 16 n P) and partial sums inside a fixed budget
-static size_t msm_batch_limit(size_t n, bool pre) {
-    uint64_t per = (uint64_t)n * 16;
-    uint64_t lim = per ? (1ull << 28) / per : 8;  // <= 2^28 references (1 GiB of refs) per launch set
-    if (lim < 1) lim = 1;
-    if (lim > (pre ? 16u : 4u)) lim = pre ? 16u : 4u;
-    return (size_t)lim;
-}
-
 static void affine_to_abi(const g1_affine& a, uint64_t xy[8], int* inf) {
     bool is_inf = G1::is_inf(a);
     for (int i = 0; i < 4; i++) {
@@ -505,14 +497,25 @@ static g1_affine abi_to_affine(const uint64_t xy[8], int inf) {
     return a;
 }
 
-void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, size_t n, const void* const* scalars,
+// k MSMs with per-polynomial base slices; launch sets are cut so that one set holds at most 2^28 point
+// references (1 GiB of refs) and at most 16 (window table) / 4 (16 window groups) polynomials
+void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, const size_t* ns, const void* const* scalars,
                const int* kinds, size_t k, uint64_t* out_xy, int* out_inf) {
     ctx->msm_ws.out.reserve(k * sizeof(g1_affine));
     g1_affine* d_out = ctx->msm_ws.out.as<g1_affine>();
-    size_t lim = msm_batch_limit(n, bases->nwin == 16);
-    for (size_t s = 0; s < k; s += lim) {
-        size_t P = k - s < lim ? k - s : lim;
-        msm_run_device(ctx, bases, offset, n, scalars + s, kinds + s, P, d_out + s);
+    const size_t maxP = bases->nwin == 16 ? 16 : 4;
+    size_t s = 0;
+    while (s < k) {
+        size_t P = 0;
+        uint64_t M = 0;
+        while (s + P < k && P < maxP) {
+            uint64_t m = (uint64_t)ns[s + P] * kind_nwin(kinds[s + P]);
+            if (P > 0 && M + m > (1ull << 28)) break;
+            M += m;
+            P++;
+        }
+        msm_run_device(ctx, bases, offsets + s, ns + s, scalars + s, kinds + s, P, d_out + s);
+        s += P;
     }
     g1_affine* h = reinterpret_cast<g1_affine*>(ctx_pinned(ctx, k * sizeof(g1_affine)));
     HIP_TRY(hipMemcpyAsync(h, d_out, k * sizeof(g1_affine), hipMemcpyDeviceToHost, ctx->stream));
@@ -615,7 +618,8 @@ int cozk_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const co
         COZK_REQUIRE(ctx && bases && scalars && out_xy, "msm_vec: bad argument");
         const void* p = scalars->d;
         int kind = scalars->kind;
-        msm_batch(ctx, bases, offset, scalars->n, &p, &kind, 1, out_xy, out_infinity);
+        size_t n = scalars->n;
+        msm_batch(ctx, bases, &offset, &n, &p, &kind, 1, out_xy, out_infinity);
     });
 }
 
@@ -625,14 +629,34 @@ int cozk_batch_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, co
         COZK_REQUIRE(ctx && bases && scalars && out_xy && k > 0, "batch_msm_vec: bad argument");
         std::vector<const void*> ptrs(k);
         std::vector<int> kinds(k);
+        std::vector<size_t> offs(k, offset), ns(k);
         size_t n = scalars[0]->n;
         for (size_t i = 0; i < k; i++) {
             // "batch commit requires all batches to have the same length" (pst13.rs:310-313)
             COZK_REQUIRE(scalars[i] && scalars[i]->n == n, "batch_msm_vec: polynomials must have equal length");
             ptrs[i] = scalars[i]->d;
             kinds[i] = scalars[i]->kind;
+            ns[i] = n;
         }
-        msm_batch(ctx, bases, offset, n, ptrs.data(), kinds.data(), k, out_xy, out_infinity);
+        msm_batch(ctx, bases, offs.data(), ns.data(), ptrs.data(), kinds.data(), k, out_xy, out_infinity);
+    });
+}
+
+int cozk_batch_msm_slices(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, const cozk_vec* const* scalars,
+                          const size_t* lens, size_t k, uint64_t* out_xy, int* out_infinity) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && bases && offsets && scalars && out_xy && k > 0, "batch_msm_slices: bad argument");
+        std::vector<const void*> ptrs(k);
+        std::vector<int> kinds(k);
+        std::vector<size_t> ns(k);
+        for (size_t i = 0; i < k; i++) {
+            COZK_REQUIRE(scalars[i], "batch_msm_slices: null scalar vector");
+            ns[i] = lens ? lens[i] : scalars[i]->n;
+            COZK_REQUIRE(ns[i] <= scalars[i]->n, "batch_msm_slices: length exceeds the scalar vector");
+            ptrs[i] = scalars[i]->d;
+            kinds[i] = scalars[i]->kind;
+        }
+        msm_batch(ctx, bases, offsets, ns.data(), ptrs.data(), kinds.data(), k, out_xy, out_infinity);
     });
 }
 
@@ -644,7 +668,7 @@ int cozk_msm(cozk_ctx* ctx, const cozk_bases* bases, size_t offset, const void* 
         ctx->scratch2.reserve(bytes ? bytes : 16);
         if (bytes) HIP_TRY(hipMemcpyAsync(ctx->scratch2.p, host_scalars, bytes, hipMemcpyHostToDevice, ctx->stream));
         const void* p = ctx->scratch2.p;
-        msm_batch(ctx, bases, offset, n, &p, &kind, 1, out_xy, out_infinity);
+        msm_batch(ctx, bases, &offset, &n, &p, &kind, 1, out_xy, out_infinity);
     });
 }
 

@@ -118,3 +118,38 @@ static inline fe fe_from_u64x4(const uint64_t v[4]) {
 static inline void fe_to_u64x4(const fe& a, uint64_t v[4]) {
     for (int i = 0; i < 4; i++) v[i] = (uint64_t)a.l[2 * i] | ((uint64_t)a.l[2 * i + 1] << 32);
 }
+
+// unique polynomial through (i, evals[i]), i = 0..n-1 (UniPoly::from_evals), n in {3, 4}
+static inline void unipoly_from_evals(const fe* ev, int n, fe* coeffs) {
+    // Lagrange on the fixed nodes 0..n-1 with small-integer inverses
+    fe inv2 = fr_two_inv();
+    if (n == 3) {
+        // c0 = e0; c2 = (e2 - 2 e1 + e0)/2; c1 = e1 - e0 - c2
+        fe c2 = Fr::mul(Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]), inv2);
+        coeffs[0] = ev[0];
+        coeffs[2] = c2;
+        coeffs[1] = Fr::sub(Fr::sub(ev[1], ev[0]), c2);
+        return;
+    }
+    // n == 4: finite differences: d1 = e1-e0, d2 = e2-2e1+e0, d3 = e3-3e2+3e1-e0
+    fe inv6;  // 6^{-1} in Montgomery form
+    {
+        const uint32_t v6[8] = {0x0aaaaaaau, 0x7d695c48u, 0xaed9b4f4u, 0x3a880fcfu,
+                                0xa9a9c517u, 0xda7526dbu, 0x69deea8eu, 0x0a67cbb3u};
+        for (int i = 0; i < 8; i++) inv6.l[i] = v6[i];
+    }
+    fe d1 = Fr::sub(ev[1], ev[0]);
+    fe d2 = Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]);
+    fe three_e2 = Fr::add(Fr::dbl(ev[2]), ev[2]), three_e1 = Fr::add(Fr::dbl(ev[1]), ev[1]);
+    fe d3 = Fr::sub(Fr::add(Fr::sub(ev[3], three_e2), three_e1), ev[0]);
+    // p(x) = e0 + d1 x + d2 x(x-1)/2 + d3 x(x-1)(x-2)/6
+    fe a3 = Fr::mul(d3, inv6);
+    fe h2 = Fr::mul(d2, inv2);
+    // x(x-1)/2 -> h2 (x^2 - x); x(x-1)(x-2)/6 -> a3 (x^3 - 3x^2 + 2x)
+    fe three_a3 = Fr::add(Fr::dbl(a3), a3);
+    coeffs[0] = ev[0];
+    coeffs[1] = Fr::add(Fr::sub(d1, h2), Fr::dbl(a3));
+    coeffs[2] = Fr::sub(h2, three_a3);
+    coeffs[3] = a3;
+}
+

@@ -346,35 +346,6 @@ static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp
     HIP_TRY(hipGetLastError());
 }
 
-// unique polynomial through (i, evals[i]), i = 0..n-1 (UniPoly::from_evals), n in {3, 4}
-static void unipoly_from_evals(const fe* ev, int n, fe* coeffs) {
-    // Lagrange on the fixed nodes 0..n-1 with small-integer inverses
-    fe inv2 = fr_two_inv();
-    if (n == 3) {
-        // c0 = e0; c2 = (e2 - 2 e1 + e0)/2; c1 = e1 - e0 - c2
-        fe c2 = Fr::mul(Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]), inv2);
-        coeffs[0] = ev[0];
-        coeffs[2] = c2;
-        coeffs[1] = Fr::sub(Fr::sub(ev[1], ev[0]), c2);
-        return;
-    }
-    // n == 4: finite differences: d1 = e1-e0, d2 = e2-2e1+e0, d3 = e3-3e2+3e1-e0
-    fe inv6 = Fr::inv(Fr::from_u64(6));
-    fe d1 = Fr::sub(ev[1], ev[0]);
-    fe d2 = Fr::add(Fr::sub(ev[2], Fr::dbl(ev[1])), ev[0]);
-    fe three_e2 = Fr::add(Fr::dbl(ev[2]), ev[2]), three_e1 = Fr::add(Fr::dbl(ev[1]), ev[1]);
-    fe d3 = Fr::sub(Fr::add(Fr::sub(ev[3], three_e2), three_e1), ev[0]);
-    // p(x) = e0 + d1 x + d2 x(x-1)/2 + d3 x(x-1)(x-2)/6
-    fe a3 = Fr::mul(d3, inv6);
-    fe h2 = Fr::mul(d2, inv2);
-    // x(x-1)/2 -> h2 (x^2 - x); x(x-1)(x-2)/6 -> a3 (x^3 - 3x^2 + 2x)
-    fe three_a3 = Fr::add(Fr::dbl(a3), a3);
-    coeffs[0] = ev[0];
-    coeffs[1] = Fr::add(Fr::sub(d1, h2), Fr::dbl(a3));
-    coeffs[2] = Fr::sub(h2, three_a3);
-    coeffs[3] = a3;
-}
-
 // ------------------------------------------------------------------ C ABI: dense polynomial
 extern "C" {
 
@@ -772,6 +743,21 @@ int cozk_layer_clone(cozk_ctx* ctx, const cozk_layer* src, cozk_layer** out) {
             HIP_TRY(hipMemcpyAsync(l->buf[0][c], src->buf[src->cur][c], src->len * sizeof(fe), hipMemcpyDeviceToDevice, ctx->stream));
         }
         *out = l;
+    });
+}
+
+int cozk_layer_as_poly(cozk_ctx* ctx, const cozk_layer* l, cozk_poly** out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && out, "layer_as_poly: bad argument");
+        cozk_poly* p = new cozk_poly();
+        p->ctx = ctx;
+        p->mode = l->mode;
+        p->len = p->orig_len = l->len;
+        p->cur = -1;
+        p->own0 = false;
+        p->a0 = l->buf[l->cur][0];
+        p->b0 = l->buf[l->cur][1];
+        *out = p;
     });
 }
 

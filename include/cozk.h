@@ -121,6 +121,13 @@ int cozk_batch_msm_vec(cozk_ctx* ctx, const cozk_bases* bases, size_t offset,
                        const cozk_vec* const* scalars, size_t k, uint64_t* out_xy,
                        int* out_infinity);
 
+/* k MSMs with a different base slice per polynomial: poly i runs over bases[offsets[i] .. +lens[i])
+ * (lens = NULL: each vector's full length).  One launch set for all `nv` MSMs of PST13 `open`
+ * (pst13.rs:445-471), whose levels live concatenated in one bases handle. */
+int cozk_batch_msm_slices(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets,
+                          const cozk_vec* const* scalars, const size_t* lens, size_t k,
+                          uint64_t* out_xy, int* out_infinity);
+
 /* G1 helpers used by the coordinator-side combine (`combine_commitment_shares`, pst13.rs:72-108;
  * `coordinate_prove`, :110-122): out = sum of k affine points */
 int cozk_g1_sum(cozk_ctx* ctx, const uint64_t* xy, const int* infinity, size_t k,
@@ -201,6 +208,60 @@ int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** ou
 int cozk_spliteq_free(cozk_spliteq* e);
 int cozk_spliteq_lens(const cozk_spliteq* e, size_t* e1_len, size_t* e2_len);
 int cozk_spliteq_bind(cozk_ctx* ctx, cozk_spliteq* e, const uint64_t r[4]);
+
+/* the layer's current coefficients as a borrowed dense polynomial (for evaluating a layer's MLE) */
+int cozk_layer_as_poly(cozk_ctx* ctx, const cozk_layer* l, cozk_poly** out);
+
+/* ---------------------------------------------------------------- network seam ------------- */
+/* Host-supplied transports for the worker drivers (libcozk's C++ host layer, csrc/host/prover.hpp).
+ * Star = MpcStarNetWorker::{send_response, receive_request} (mpc-net/src/mpc_star.rs:5-66); payloads
+ * are ark-serialize uncompressed bytes.  Ring = Rep3Network reshare (send to next, receive from prev;
+ * mpc-core/src/protocols/rep3/arithmetic.rs:144-164) on DEVICE buffers, e.g. an RCCL
+ * ncclSend/ncclRecv pair.  Callbacks return 0 on success. */
+typedef struct cozk_star_net {
+    void* user;
+    int (*send_response)(void* user, const void* bytes, size_t len);
+    int (*receive_request)(void* user, void* buf, size_t cap, size_t* out_len);
+} cozk_star_net;
+typedef struct cozk_ring_net {
+    void* user;
+    int (*reshare)(void* user, const void* dev_send, void* dev_recv, size_t nbytes);
+} cozk_ring_net;
+
+/* ---------------------------------------------------------------- in-process harness ------- */
+/* Counterpart of the reference's runner (co-jolt/examples/rep3_jolt.rs:118-317, run_3_party_jolt.sh):
+ * synthesises one trace's witness, runs every party on its own thread / ctx and the
+ * coordinator on the caller's thread, and verifies the assembled proof. */
+typedef struct cozk_harness cozk_harness;
+typedef struct cozk_harness_config {
+    int mode;          /* COZK_MODE_PLAIN: one party (plain prover); COZK_MODE_REP3: three parties */
+    int log_n;         /* padded trace length N = 2^log_n ("cycles") */
+    int n_fr;          /* committed polynomials with uniform Fr scalars (shared in REP3) */
+    int n_u16;         /* public u16-valued polynomials */
+    int n_u32;         /* public u32-valued polynomials */
+    int n_flags;       /* public 0/1 flag polynomials */
+    int n_small;       /* shared polynomials of length N/16 (own batch_commit + own opening) */
+    int gp_batch;      /* circuits in the dense grand product */
+    int gp_log_leaves; /* log2(interleaved leaves per circuit) */
+    int precompute;    /* build the 16-window SRS table */
+    int devices[3];    /* HIP device per party */
+    uint64_t seed;
+} cozk_harness_config;
+typedef struct cozk_harness_result {
+    int verified; /* 1 accepted, 0 rejected, -1 verifier not run */
+    double wall_ms;
+    /* worker-side phase times, max over parties */
+    double t_commit_ms, t_gp_construct_ms, t_gp_prove_ms, t_eval_ms, t_open_ms, t_worker_ms;
+    uint64_t bytes_star_up, bytes_star_down, bytes_ring, star_messages;
+    uint64_t proof_len;
+    uint8_t proof_digest[32]; /* SHA-256 of the serialized proof */
+} cozk_harness_result;
+int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out);
+const char* cozk_harness_error(const cozk_harness* h);
+int cozk_harness_destroy(cozk_harness* h);
+int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res);
+int cozk_harness_proof_bytes(const cozk_harness* h, uint8_t* out, size_t cap);
+cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party);
 
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation) on the ctx stream, for
