@@ -106,7 +106,8 @@ SIGNATURES = {
     "cozk_spliteq_lens": (_i, [_vp, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "cozk_spliteq_bind": (_i, [_vp, _vp, _vp]),
     "cozk_prof_enable": (_i, [_vp, _i]),
-    "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
+    "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    "cozk_layer_as_poly": (_i, [_vp, _vp, _pp]),
     "cozk_bench_montmul": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(ctypes.c_double)]),
 }
 

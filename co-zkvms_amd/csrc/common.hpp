@@ -76,6 +76,7 @@ struct cozk_ctx {
     double prof_ms = 0.0;
     uint64_t prof_launches = 0;
     uint64_t prof_units = 0;  // point additions issued by those launches
+    uint64_t prof_alg_bytes = 0;  // algorithmic bytes of those launches: n * (64 B base + scalar bytes) per MSM
 };
 
 struct cozk_bases {

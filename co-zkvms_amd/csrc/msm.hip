@@ -450,6 +450,7 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
         ctx->prof_events.push_back({e0, e1});
         ctx->prof_launches += 1;
         ctx->prof_units += M;
+        for (size_t p = 0; p < P; p++) ctx->prof_alg_bytes += (uint64_t)ns[p] * (64 + scalar_kind_bytes(kinds[p]));
     }
     // further levels until the worst case leaves one value per bucket
     uint64_t cnt = (bound + L0 - 1) / L0;
@@ -712,10 +713,11 @@ int cozk_prof_enable(cozk_ctx* ctx, int on) {
         ctx->prof_ms = 0;
         ctx->prof_launches = 0;
         ctx->prof_units = 0;
+        ctx->prof_alg_bytes = 0;
     });
 }
 
-int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds) {
+int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds, uint64_t* alg_bytes) {
     return cozk_guard(ctx, [&] {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         for (auto& pr : ctx->prof_events) {
@@ -729,6 +731,7 @@ int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t
         if (launches) *launches = ctx->prof_launches;
         if (total_ms) *total_ms = ctx->prof_ms;
         if (point_adds) *point_adds = ctx->prof_units;
+        if (alg_bytes) *alg_bytes = ctx->prof_alg_bytes;
     });
 }
 

@@ -102,8 +102,9 @@ class Context:
         n = ctypes.c_uint64()
         ms = ctypes.c_double()
         adds = ctypes.c_uint64()
-        self.check(self._l.cozk_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(adds)))
-        return n.value, ms.value, adds.value
+        nbytes = ctypes.c_uint64()
+        self.check(self._l.cozk_prof_read(self.h, ctypes.byref(n), ctypes.byref(ms), ctypes.byref(adds), ctypes.byref(nbytes)))
+        return n.value, ms.value, adds.value, nbytes.value
 
     def bench_montmul(self, lanes, iters, variant=0):
         ms = ctypes.c_double()

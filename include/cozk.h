@@ -264,10 +264,12 @@ int cozk_harness_proof_bytes(const cozk_harness* h, uint8_t* out, size_t cap);
 cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party);
 
 /* ---------------------------------------------------------------- profiling ---------------- */
-/* HIP-event timing of the dominant kernel (MSM bucket accumulation) on the ctx stream, for
- * bench.py's roofline object: launches, total ms, point additions issued. */
+/* HIP-event timing of the dominant kernel (MSM bucket accumulation, k_msm_accum0) on the ctx stream,
+ * for bench.py's roofline object: launches, total ms, point additions issued, and the algorithmic
+ * bytes of those launches (n x (64 B base + scalar bytes) per MSM). */
 int cozk_prof_enable(cozk_ctx* ctx, int on);
-int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds);
+int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds,
+                   uint64_t* alg_bytes);
 /* Fq Montgomery-multiply micro-benchmark: `iters` dependent products per lane on `lanes` lanes;
  * returns elapsed ms (HIP events) -- the measured integer-ALU peak. */
 int cozk_bench_montmul(cozk_ctx* ctx, size_t lanes, int iters, int variant, double* out_ms);

@@ -21,7 +21,7 @@ for logn in (16, 18, 20):
         t0 = time.time()
         B.batch_msm_raw(vs[:k])
         dt = time.time() - t0
-        nl, kms, adds = ctx.prof_read()
+        nl, kms, adds, _ = ctx.prof_read()
         print(f"msm 2^{logn} x{k}: {dt*1e3:.2f} ms total, {dt*1e3/k:.2f} ms/msm; accum0 {kms:.2f} ms for {adds} adds -> {adds/kms/1e6:.2f} Gadd/s", flush=True)
     for kind, bits in ((m.SCALAR_U16, 0), (m.SCALAR_U32, 0), (m.SCALAR_U8, 1)):
         v = m.Vec.random(ctx, n, seed=5, kind=kind, max_bits=bits)
