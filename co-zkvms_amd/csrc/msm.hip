@@ -168,7 +168,162 @@ __global__ void __launch_bounds__(TPB) k_msm_scatter(const void* scalars, size_t
     });
 }
 
-// ------------------------------------------------------------------ scans (single block)
+// ------------------------------------------------------------------ LDS-privatised counting sort
+// With the window table every digit of a polynomial lands in ONE group of 2^15 buckets, and a
+// 2^15 x u32 histogram is exactly 128 KiB -- it fits the 160 KiB LDS of a CDNA4 CU.  One 1024-thread
+// workgroup per CU keeps the whole histogram in LDS: digits are counted with LDS atomics (no HBM
+// traffic, no global contention even for 0/1 columns where every lane hits bucket 0), then flushed
+// with one global atomic per non-empty (workgroup, bucket).  The scatter pass recounts, claims a
+// contiguous range per (workgroup, bucket) with one returning global atomic, and hands out slots
+// with returning LDS atomics.  Global atomics drop from 2 x 16 n to <= 2 x 2^15 x workgroups.
+struct MsmPolyDesc {
+    const void* scalars;
+    uint32_t n;         // scalars in this polynomial's slice
+    uint32_t base_off;  // first SRS index of the slice
+    uint32_t group;     // bucket group (= polynomial index inside the launch set)
+    uint32_t pad;
+};
+static constexpr int LTPB = 1024;
+
+template <int KIND>
+__global__ void __launch_bounds__(LTPB) k_msm_hist_lds(const MsmPolyDesc* __restrict__ descs, uint32_t* __restrict__ hist) {
+    __shared__ uint32_t lh[NB];
+    const MsmPolyDesc d = descs[blockIdx.y];
+    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) lh[b] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+        for_each_digit<KIND>(d.scalars, i, [&](int, uint32_t mag, bool) {
+            if (mag != 0) atomicAdd(&lh[mag - 1u], 1u);
+        });
+    }
+    __syncthreads();
+    uint32_t* h = hist + (size_t)d.group * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) {
+        uint32_t c = lh[b];
+        if (c) atomicAdd(&h[b], c);
+    }
+}
+
+template <int KIND>
+__global__ void __launch_bounds__(LTPB) k_msm_scatter_lds(const MsmPolyDesc* __restrict__ descs, uint32_t* __restrict__ cursor,
+                                                       uint32_t* __restrict__ refs, uint32_t table_n) {
+    __shared__ uint32_t lh[NB];
+    const MsmPolyDesc d = descs[blockIdx.y];
+    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) lh[b] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+        for_each_digit<KIND>(d.scalars, i, [&](int, uint32_t mag, bool) {
+            if (mag != 0) atomicAdd(&lh[mag - 1u], 1u);
+        });
+    }
+    __syncthreads();
+    uint32_t* cur = cursor + (size_t)d.group * NB;
+    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) {
+        uint32_t c = lh[b];
+        lh[b] = c ? atomicAdd(&cur[b], c) : 0u;  // this workgroup's slot range inside bucket b
+    }
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+        for_each_digit<KIND>(d.scalars, i, [&](int k, uint32_t mag, bool negative) {
+            if (mag != 0) {
+                uint32_t pos = atomicAdd(&lh[mag - 1u], 1u);
+                uint32_t ref = (uint32_t)k * table_n + d.base_off + (uint32_t)i;
+                refs[pos] = ref | (negative ? 0x80000000u : 0u);
+            }
+        });
+    }
+}
+
+// ------------------------------------------------------------------ scans
+// exclusive prefix over nb counters in three small launches: per-block sums, one-block scan of the
+// block sums, per-block rescan + offset.  1024 counters per block (256 threads x uint4).
+// FROM_OFFSETS: the counter of bucket b is ceil((in[b+1] - in[b]) / L) (segments of the next level).
+static constexpr uint32_t SCAN_PER_BLOCK = 1024;
+
+template <bool FROM_OFFSETS>
+static __device__ __forceinline__ void scan_load4(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t b0, uint32_t c[4]) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t b = b0 + k;
+        if (b >= nb) c[k] = 0;
+        else if (FROM_OFFSETS) c[k] = (in[b + 1] - in[b] + L - 1u) / L;
+        else c[k] = in[b];
+    }
+}
+
+static __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, uint32_t* sh4, uint32_t* total) {
+    // inclusive wave scan
+    uint32_t x = v;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        uint32_t y = __shfl_up(x, off);
+        if ((int)(threadIdx.x & 63) >= off) x += y;
+    }
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 63) sh4[w] = x;
+    __syncthreads();
+    uint32_t base = 0;
+    for (int i = 0; i < w; i++) base += sh4[i];
+    if (total) *total = sh4[0] + sh4[1] + sh4[2] + sh4[3];
+    __syncthreads();
+    return base + x - v;
+}
+
+template <bool FROM_OFFSETS>
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t* __restrict__ bsums) {
+    __shared__ uint32_t sh4[4];
+    uint32_t c[4];
+    scan_load4<FROM_OFFSETS>(in, nb, L, blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4, c);
+    uint32_t tot;
+    (void)block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], sh4, &tot);
+    if (threadIdx.x == 0) bsums[blockIdx.x] = tot;
+}
+
+// exclusive scan of the block sums in place (nblk <= 16384); writes the grand total to *total_out
+__global__ void __launch_bounds__(1024) k_scan_top(uint32_t* bsums, uint32_t nblk, uint32_t* total_out) {
+    __shared__ uint32_t sh[1024];
+    uint32_t tid = threadIdx.x;
+    uint32_t per = (nblk + 1023u) / 1024u;
+    uint32_t b0 = tid * per, b1 = min(nblk, b0 + per);
+    uint32_t sum = 0;
+    for (uint32_t b = b0; b < b1; b++) sum += bsums[b];
+    sh[tid] = sum;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= d ? sh[tid - d] : 0;
+        __syncthreads();
+        sh[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = sh[tid] - sum;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t c = bsums[b];
+        bsums[b] = run;
+        run += c;
+    }
+    if (tid == 1023) *total_out = sh[1023];
+}
+
+template <bool FROM_OFFSETS>
+__global__ void __launch_bounds__(256) k_scan_final(const uint32_t* in, uint32_t nb, uint32_t L, const uint32_t* __restrict__ bsums,
+                                                  uint32_t* off, uint32_t* cursor) {
+    __shared__ uint32_t sh4[4];
+    uint32_t c[4];
+    uint32_t b0 = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4;
+    scan_load4<FROM_OFFSETS>(in, nb, L, b0, c);
+    uint32_t run = bsums[blockIdx.x] + block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], sh4, nullptr);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint32_t b = b0 + k;
+        if (b < nb) {
+            off[b] = run;
+            if (cursor) cursor[b] = run;
+        }
+        run += c[k];
+    }
+}
+
+// legacy single-block scan (kept for tiny inputs and as the reference the multi-block one is tested against)
 // off[b] = exclusive prefix of cnt, off[nb] = total; cursor (optional) = copy of off[0..nb)
 template <bool FROM_OFFSETS>
 __global__ void __launch_bounds__(1024) k_scan(const uint32_t* in, uint32_t nb, uint32_t L, uint32_t* off,
@@ -404,7 +559,7 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
     uint32_t L0 = (uint32_t)(M >> 18);
     if (L0 < 8) L0 = 8;
     if (L0 > 64) L0 = 64;
-    const uint32_t L1 = 32;
+    const uint32_t L1 = 64;
 
     ws.hist.reserve((size_t)(nb + 1) * 4);
     ws.off0.reserve((size_t)(nb + 1) * 4);
@@ -422,22 +577,66 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
     uint32_t* hist = ws.hist.as<uint32_t>();
     uint32_t* off0 = ws.off0.as<uint32_t>();
     uint32_t* refs = ws.refs.as<uint32_t>();
+    const uint32_t nscan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    ws.ptrs.reserve((size_t)nscan_blocks * 4 + P * sizeof(MsmPolyDesc) + 64);
+    uint32_t* bsums = ws.ptrs.as<uint32_t>();
+    MsmPolyDesc* d_descs = reinterpret_cast<MsmPolyDesc*>(((uintptr_t)(bsums + nscan_blocks) + 15) & ~(uintptr_t)15);
+    auto scan = [&](bool from_offsets, const uint32_t* in, uint32_t L, uint32_t* off, uint32_t* cursor) {
+        if (from_offsets) {
+            k_scan_sums<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+            k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
+            k_scan_final<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+        } else {
+            k_scan_sums<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+            k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
+            k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+        }
+    };
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 1) * 4, st));
-    for (size_t p = 0; p < P; p++) {
-        uint32_t* h = hist + (size_t)p * G * NB;
-        if (ns[p]) KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], ns[p], h, pre ? 0 : 1));
-    }
-    // hist doubles as the scatter cursor after the scan
-    k_scan<false><<<1, 1024, 0, st>>>(hist, nb, 1, off0, hist);
-    for (size_t p = 0; p < P; p++) {
-        uint32_t* cur = hist + (size_t)p * G * NB;
-        if (ns[p]) KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], ns[p], cur, refs, pre ? 0 : 1, (uint32_t)bases->n,
-                                                           (uint32_t)offsets[p]));
+    if (pre) {
+        // LDS-privatised counting sort: one launch per scalar kind, grid = (workgroups per polynomial, polynomials)
+        std::vector<MsmPolyDesc> descs;
+        std::vector<std::pair<int, std::pair<uint32_t, uint32_t>>> runs;  // kind -> (first desc, count)
+        size_t max_n = 0;
+        for (int kind = 0; kind <= COZK_SCALAR_I64; kind++) {
+            uint32_t first = (uint32_t)descs.size();
+            for (size_t p = 0; p < P; p++)
+                if (kinds[p] == kind && ns[p]) {
+                    descs.push_back(MsmPolyDesc{scalars[p], (uint32_t)ns[p], (uint32_t)offsets[p], (uint32_t)p, 0});
+                    if (ns[p] > max_n) max_n = ns[p];
+                }
+            if (descs.size() > first) runs.push_back({kind, {first, (uint32_t)descs.size() - first}});
+        }
+        HIP_TRY(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(MsmPolyDesc), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));  // descs is a stack vector
+        uint32_t wgs = (uint32_t)((max_n + 4095) / 4096);  // >= 4096 scalars per workgroup
+        if (wgs < 1) wgs = 1;
+        if (wgs > 64) wgs = 64;
+        for (auto& r : runs) {
+            dim3 grid(wgs, r.second.second);
+            KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist)));
+        }
+        scan(false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
+        for (auto& r : runs) {
+            dim3 grid(wgs, r.second.second);
+            KIND_DISPATCH(r.first, (k_msm_scatter_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist, refs, (uint32_t)bases->n)));
+        }
+    } else {
+        for (size_t p = 0; p < P; p++) {
+            uint32_t* h = hist + (size_t)p * G * NB;
+            if (ns[p]) KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], ns[p], h, 1));
+        }
+        scan(false, hist, 1, off0, hist);
+        for (size_t p = 0; p < P; p++) {
+            uint32_t* cur = hist + (size_t)p * G * NB;
+            if (ns[p]) KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], ns[p], cur, refs, 1, (uint32_t)bases->n,
+                                                               (uint32_t)offsets[p]));
+        }
     }
     // level 0
     uint32_t* offA = ws.offA.as<uint32_t>();
     uint32_t* offB = ws.offB.as<uint32_t>();
-    k_scan<true><<<1, 1024, 0, st>>>(off0, nb, L0, offA, nullptr);
+    scan(true, off0, L0, offA, nullptr);
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_enabled) {
         HIP_TRY(hipEventCreate(&e0));
@@ -461,7 +660,7 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
     uint32_t* nxt_off = offB;
     while (cnt > 1) {
         uint64_t nseg = maxseg / L1 + nb;
-        k_scan<true><<<1, 1024, 0, st>>>(cur_off, nb, L1, nxt_off, nullptr);
+        scan(true, cur_off, L1, nxt_off, nullptr);
         k_msm_accumN<<<cdiv(nseg, TPB), TPB, 0, st>>>(cur_items, cur_off, nxt_off, nb, L1, nxt_items);
         std::swap(cur_items, nxt_items);
         std::swap(cur_off, nxt_off);
