@@ -315,6 +315,31 @@ __global__ void __launch_bounds__(PT) k_eq_expand(const fe* __restrict__ in, fe*
     fe_store(out + 2 * i + 1, hi);
 }
 
+// whole EqPolynomial::evals table in one launch (one workgroup; tables here are <= 2^13 entries:
+// the two halves of a split-eq): level j doubles the table in place from the top index down
+__global__ void __launch_bounds__(1024) k_eq_build(const fe* __restrict__ r, int nv, fe* __restrict__ out) {
+    if (threadIdx.x == 0) fe_store(out, Fr::one());
+    __syncthreads();
+    size_t n = 1;
+    for (int j = 0; j < nv; j++) {
+        fe rj = fe_load(r + j);
+        // read phase, then write phase: entry i expands to (2i, 2i+1)
+        fe e[8];
+        int cnt = 0;
+        for (size_t i = threadIdx.x; i < n; i += 1024) e[cnt++] = fe_load(out + i);
+        __syncthreads();
+        cnt = 0;
+        for (size_t i = threadIdx.x; i < n; i += 1024) {
+            fe hi = Fr::mul(e[cnt], rj);
+            fe_store(out + 2 * i, Fr::sub(e[cnt], hi));
+            fe_store(out + 2 * i + 1, hi);
+            cnt++;
+        }
+        __syncthreads();
+        n *= 2;
+    }
+}
+
 // ------------------------------------------------------------------ host helpers
 static fe* dev_alloc_fe(size_t n) {
     void* p = nullptr;
@@ -332,6 +357,21 @@ static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
 
 // build an eq table on device: out (len 2^nv) from point r (host), big-endian
 static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp) {
+    if (nv <= 13) {
+        // small table: one launch; the point travels through `tmp` (tmp has >= 2^nv entries; nv >= 0)
+        fe* rd = tmp;
+        if (nv > 0) {
+            if ((size_t)nv > ((size_t)1 << nv)) {  // nv = 1..3: 2^nv may be smaller than nv entries of scratch
+                ctx->scratch.reserve(64 * sizeof(fe));
+                rd = ctx->scratch.as<fe>();
+            }
+            HIP_TRY(hipMemcpyAsync(rd, r, (size_t)nv * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));  // r is caller-owned host memory
+        }
+        k_eq_build<<<1, 1024, 0, ctx->stream>>>(rd, nv, out);
+        HIP_TRY(hipGetLastError());
+        return;
+    }
     fe one = Fr::one();
     fe* cur = (nv % 2 == 0) ? out : tmp;  // ping-pong so that the last level lands in `out`
     fe* nxt = (nv % 2 == 0) ? tmp : out;
