@@ -8,5 +8,6 @@ from ._lib import (CozkError, SCALAR_FR, SCALAR_U8, SCALAR_U16, SCALAR_U32, SCAL
 from .engine import (Context, Vec, Bases, FR_MOD, FQ_MOD, fr_to_mont_limbs, mont_limbs_to_int,
                      point_to_abi, point_from_abi)
 from .poly import (Rep3DensePolynomial, Rep3DenseInterleavedPolynomial, SplitEqPolynomial, eq_evals,
-                   open_quadratic_evals, pst_fold)
+                   open_quadratic_evals, pst_fold, prod_sumcheck_evals, spartan_first_round, spartan_second_round,
+                   sparse_matvec3)
 from .harness import Harness, HarnessConfig, HarnessResult

@@ -89,6 +89,10 @@ SIGNATURES = {
     "cozk_poly_dot_product_with_public": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_poly_linear_combination": (_i, [_vp, _vp, _vp, _sz, _i, _i, _pp]),
     "cozk_open_quadratic_evals": (_i, [_vp, _vp, _vp, _sz, _vp]),
+    "cozk_prod_sumcheck_evals": (_i, [_vp, _vp, _sz, _i, _vp]),
+    "cozk_spartan_first_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cozk_spartan_second_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "cozk_sparse_matvec3": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _pp, _pp, _pp]),
     "cozk_pst_fold": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_layer_create": (_i, [_vp, _i, _vp, _vp, _i, _pp]),
     "cozk_layer_free": (_i, [_vp]),

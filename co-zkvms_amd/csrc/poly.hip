@@ -287,6 +287,139 @@ __global__ void __launch_bounds__(PT) k_mul_vec_local(const fe* __restrict__ xa,
     fe_store(out + j, v);
 }
 
+// ------------------------------------------------------------------ kernels: generic product rounds
+// One round of `prove_arbitrary_worker` (co-jolt/src/subprotocols/sumcheck.rs:168-246) for the
+// comb_funcs the reference uses -- a product of m polynomials of which at most one is shared
+// (Spartan inner / shift sumchecks r1cs/spartan/worker.rs:162-235, output check
+// read_write_memory/worker.rs:149-164): evaluations at x = 0, 2, .., degree of
+// sum_i prod_j P_j(x; i) with HighToLow pairs (i, i + half) (sumcheck_evals, dense_mlpoly.rs:113-147).
+// partial[e * gridDim.x + block]; shared factor enters as (a + b), TWO_INV applied by the finisher.
+template <int NC, int M>
+__global__ void __launch_bounds__(PT) k_prod_round(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
+                                                int shared_idx, size_t half, int degree, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    fe acc[4];
+    for (int e = 0; e < 4; e++) acc[e] = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < half; i += (size_t)gridDim.x * PT) {
+        fe cur[M], step[M];
+        for (int j = 0; j < M; j++) {
+            fe lo, hi;
+            if (NC == 2 && j == shared_idx) {
+                lo = Fr::add(fe_load(pa[j] + i), fe_load(pb[j] + i));
+                hi = Fr::add(fe_load(pa[j] + i + half), fe_load(pb[j] + i + half));
+            } else {
+                lo = fe_load(pa[j] + i);
+                hi = fe_load(pa[j] + i + half);
+            }
+            step[j] = Fr::sub(hi, lo);
+            cur[j] = lo;
+        }
+        for (int e = 0; e < degree; e++) {
+            // points 0, 2, 3, ...: after the first evaluation jump to x = 2
+            if (e == 1)
+                for (int j = 0; j < M; j++) cur[j] = Fr::add(Fr::add(cur[j], step[j]), step[j]);
+            else if (e > 1)
+                for (int j = 0; j < M; j++) cur[j] = Fr::add(cur[j], step[j]);
+            fe prod = cur[0];
+            for (int j = 1; j < M; j++) prod = Fr::mul(prod, cur[j]);
+            acc[e] = Fr::add(acc[e], prod);
+        }
+    }
+    for (int e = 0; e < degree; e++) {
+        fe v = fr_block_sum(acc[e], sh4);
+        if (threadIdx.x == 0) fe_store(partial + (size_t)e * gridDim.x + blockIdx.x, v);
+    }
+}
+
+// co-spartan sumcheck #1 round (co-noir-spartan/co-spartan/src/sumcheck.rs:171-280): evaluations at
+// X = 0..3 of sum_b [ (A x B)(X) * pub(X) - into_additive(C(X) * pub(X)) ], LowToHigh pairs (2b, 2b+1).
+// The -C term is accumulated as (c.a + c.b) * pub separately so that TWO_INV is applied once per sum.
+template <int NC>
+__global__ void __launch_bounds__(PT) k_spartan_first(const fe* __restrict__ aa, const fe* __restrict__ ab, const fe* __restrict__ ba,
+                                                   const fe* __restrict__ bb, const fe* __restrict__ ca, const fe* __restrict__ cb,
+                                                   const fe* __restrict__ pub, size_t half, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    fe accp[4], accc[4];
+    for (int e = 0; e < 4; e++) {
+        accp[e] = Fr::zero();
+        accc[e] = Fr::zero();
+    }
+    for (size_t b = (size_t)blockIdx.x * PT + threadIdx.x; b < half; b += (size_t)gridDim.x * PT) {
+        Sh<NC> A = sh_load<NC>(aa, ab, 2 * b), B = sh_load<NC>(ba, bb, 2 * b), C = sh_load<NC>(ca, cb, 2 * b);
+        Sh<NC> sA = sh_sub<NC>(sh_load<NC>(aa, ab, 2 * b + 1), A), sB = sh_sub<NC>(sh_load<NC>(ba, bb, 2 * b + 1), B),
+               sC = sh_sub<NC>(sh_load<NC>(ca, cb, 2 * b + 1), C);
+        fe P = fe_load(pub + 2 * b);
+        fe sP = Fr::sub(fe_load(pub + 2 * b + 1), P);
+        for (int e = 0; e < 4; e++) {
+            accp[e] = Fr::add(accp[e], Fr::mul(sh_local_mul<NC>(A, B), P));
+            accc[e] = Fr::add(accc[e], Fr::mul(sh_ab_sum<NC>(C), P));
+            A = sh_add<NC>(A, sA);
+            B = sh_add<NC>(B, sB);
+            C = sh_add<NC>(C, sC);
+            P = Fr::add(P, sP);
+        }
+    }
+    for (int e = 0; e < 4; e++) {
+        fe v = fr_block_sum(accp[e], sh4);
+        if (threadIdx.x == 0) fe_store(partial + (size_t)e * gridDim.x + blockIdx.x, v);
+        fe w = fr_block_sum(accc[e], sh4);
+        if (threadIdx.x == 0) fe_store(partial + (size_t)(4 + e) * gridDim.x + blockIdx.x, w);
+    }
+}
+
+// co-spartan sumcheck #2 round (sumcheck.rs:282-395): Rep3 evaluations at X = 0..2 of
+// sum_b z(X) * (alpha a(X) + beta b(X) + gamma c(X)); component k of the share lands in partial rows 3k..3k+2
+template <int NC>
+__global__ void __launch_bounds__(PT) k_spartan_second(const fe* __restrict__ za, const fe* __restrict__ zb, const fe* __restrict__ pa,
+                                                    const fe* __restrict__ pbv, const fe* __restrict__ pc, fe c0, fe c1, fe c2,
+                                                    size_t half, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    fe acc[NC][3];
+    for (int k = 0; k < NC; k++)
+        for (int e = 0; e < 3; e++) acc[k][e] = Fr::zero();
+    for (size_t b = (size_t)blockIdx.x * PT + threadIdx.x; b < half; b += (size_t)gridDim.x * PT) {
+        Sh<NC> Z = sh_load<NC>(za, zb, 2 * b);
+        Sh<NC> sZ = sh_sub<NC>(sh_load<NC>(za, zb, 2 * b + 1), Z);
+        fe A = fe_load(pa + 2 * b), B = fe_load(pbv + 2 * b), C = fe_load(pc + 2 * b);
+        fe sA = Fr::sub(fe_load(pa + 2 * b + 1), A), sB = Fr::sub(fe_load(pbv + 2 * b + 1), B), sC = Fr::sub(fe_load(pc + 2 * b + 1), C);
+        for (int e = 0; e < 3; e++) {
+            fe lin = Fr::add(Fr::add(Fr::mul(A, c0), Fr::mul(B, c1)), Fr::mul(C, c2));
+            for (int k = 0; k < NC; k++) acc[k][e] = Fr::add(acc[k][e], Fr::mul(Z.c[k], lin));
+            Z = sh_add<NC>(Z, sZ);
+            A = Fr::add(A, sA);
+            B = Fr::add(B, sB);
+            C = Fr::add(C, sC);
+        }
+    }
+    for (int k = 0; k < NC; k++)
+        for (int e = 0; e < 3; e++) {
+            fe v = fr_block_sum(acc[k][e], sh4);
+            if (threadIdx.x == 0) fe_store(partial + (size_t)(3 * k + e) * gridDim.x + blockIdx.x, v);
+        }
+}
+
+// zero_round (co-noir-spartan/co-spartan/src/worker.rs:153-182): za[row] = sum_nnz val_a * z[col] (same for
+// b, c) on shares, CSR rows (field sums are order-independent, so COO vs CSR order cannot change a bit)
+template <int NC>
+__global__ void __launch_bounds__(PT) k_sparse_matvec3(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                    const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
+                                                    const fe* __restrict__ za, const fe* __restrict__ zb, size_t nrows,
+                                                    fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1) {
+    size_t r = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (r >= nrows) return;
+    Sh<NC> A, B, C;
+    for (int k = 0; k < NC; k++) A.c[k] = B.c[k] = C.c[k] = Fr::zero();
+    for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+        Sh<NC> z = sh_load<NC>(za, zb, col[e]);
+        A = sh_add<NC>(A, sh_mul_public<NC>(z, fe_load(va + e)));
+        B = sh_add<NC>(B, sh_mul_public<NC>(z, fe_load(vb + e)));
+        C = sh_add<NC>(C, sh_mul_public<NC>(z, fe_load(vc + e)));
+    }
+    sh_store<NC>(oa0, oa1, r, A);
+    sh_store<NC>(ob0, ob1, r, B);
+    sh_store<NC>(oc0, oc1, r, C);
+}
+
 // ------------------------------------------------------------------ kernels: split-eq tables
 __global__ void __launch_bounds__(PT) k_fold_pairs(const fe* __restrict__ in, fe* __restrict__ out, size_t n_out, fe r) {
     size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
@@ -700,6 +833,145 @@ int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys, cons
         std::vector<fe> h(2 * k);
         fetch_fe(ctx, res, 2 * k, h.data());
         for (size_t i = 0; i < 2 * k; i++) fe_to_u64x4(h[i], out + 4 * i);
+    });
+}
+
+// one round of prove_arbitrary_worker's evaluation loop (sumcheck.rs:189-215) for a product of m
+// polynomials (<= 4), at most one of them REP3: out[e] = additive evaluation at x = 0, 2, .., degree
+// (e = 0..degree-1).  All polynomials must have the same (current) length; HighToLow.
+int cozk_prod_sumcheck_evals(cozk_ctx* ctx, const cozk_poly* const* polys, size_t m, int degree, uint64_t* out) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && polys && out && m >= 1 && m <= 4 && degree >= 1 && degree <= 4, "prod_sumcheck: bad argument");
+        size_t len = polys[0]->len;
+        int shared = -1;
+        const fe* ha[4] = {nullptr, nullptr, nullptr, nullptr};
+        const fe* hb[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (size_t j = 0; j < m; j++) {
+            COZK_REQUIRE(polys[j] && polys[j]->len == len && len >= 2, "prod_sumcheck: length mismatch");
+            ha[j] = poly_a(polys[j]);
+            hb[j] = poly_b(polys[j]);
+            if (polys[j]->mode == COZK_MODE_REP3) {
+                COZK_REQUIRE(shared < 0, "prod_sumcheck: at most one shared factor (a shared x shared product needs a reshare)");
+                shared = (int)j;
+            }
+        }
+        size_t half = len / 2;
+        unsigned gx = grid_capped(half);
+        if (gx > 512) gx = 512;
+        ctx->scratch.reserve(8 * sizeof(void*) + (4 * (size_t)gx + 4) * sizeof(fe) + 64);
+        const fe** da = (const fe**)ctx->scratch.p;
+        const fe** db = da + 4;
+        fe* partial = (fe*)(((uintptr_t)(db + 4) + 31) & ~(uintptr_t)31);
+        fe* res = partial + 4 * (size_t)gx;
+        HIP_TRY(hipMemcpyAsync(da, ha, 4 * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipMemcpyAsync(db, hb, 4 * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+#define PROD_LAUNCH(NCV, MV) k_prod_round<NCV, MV><<<gx, PT, 0, ctx->stream>>>(da, db, shared, half, degree, partial)
+        if (shared >= 0) {
+            switch (m) { case 1: PROD_LAUNCH(2, 1); break; case 2: PROD_LAUNCH(2, 2); break; case 3: PROD_LAUNCH(2, 3); break; default: PROD_LAUNCH(2, 4); }
+        } else {
+            switch (m) { case 1: PROD_LAUNCH(1, 1); break; case 2: PROD_LAUNCH(1, 2); break; case 3: PROD_LAUNCH(1, 3); break; default: PROD_LAUNCH(1, 4); }
+        }
+#undef PROD_LAUNCH
+        k_finish_sums<<<(unsigned)degree, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), shared >= 0 ? 1 : 0, res);
+        HIP_TRY(hipGetLastError());
+        fe h[4];
+        fetch_fe(ctx, res, (size_t)degree, h);
+        for (int e = 0; e < degree; e++) fe_to_u64x4(h[e], out + 4 * e);
+    });
+}
+
+// Rep3Sumcheck::first_sumcheck_prove_round evaluations (co-spartan/src/sumcheck.rs:171-280), before the
+// additive zero-mask: out[t] for X = t = 0..3.  za, zb, zc share polys (same mode), pub a PLAIN poly.
+int cozk_spartan_first_round(cozk_ctx* ctx, const cozk_poly* za, const cozk_poly* zb, const cozk_poly* zc, const cozk_poly* pub,
+                             uint64_t out[16]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && za && zb && zc && pub && out && pub->mode == COZK_MODE_PLAIN && za->mode == zb->mode && za->mode == zc->mode &&
+                         za->len == zb->len && za->len == zc->len && za->len == pub->len && za->len >= 2,
+                     "spartan_first_round: bad argument");
+        size_t half = za->len / 2;
+        unsigned gx = grid_capped(half);
+        if (gx > 512) gx = 512;
+        ctx->scratch.reserve((8 * (size_t)gx + 8) * sizeof(fe));
+        fe* partial = ctx->scratch.as<fe>();
+        fe* res = partial + 8 * (size_t)gx;
+        if (za->mode == COZK_MODE_REP3)
+            k_spartan_first<2><<<gx, PT, 0, ctx->stream>>>(poly_a(za), poly_b(za), poly_a(zb), poly_b(zb), poly_a(zc), poly_b(zc), poly_a(pub), half, partial);
+        else
+            k_spartan_first<1><<<gx, PT, 0, ctx->stream>>>(poly_a(za), nullptr, poly_a(zb), nullptr, poly_a(zc), nullptr, poly_a(pub), half, partial);
+        k_finish_sums<<<8, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        HIP_TRY(hipGetLastError());
+        fe h[8];
+        fetch_fe(ctx, res, 8, h);
+        for (int e = 0; e < 4; e++) {
+            fe c = za->mode == COZK_MODE_REP3 ? Fr::mul(h[4 + e], fr_two_inv()) : h[4 + e];
+            fe_to_u64x4(Fr::sub(h[e], c), out + 4 * e);
+        }
+    });
+}
+
+// Rep3Sumcheck::second_sumcheck_prove_round evaluations (sumcheck.rs:282-395), before the Rep3 mask:
+// out_a[t], out_b[t] for X = t = 0..2 (out_b = 0 for PLAIN).  coef = (alpha, beta, gamma), 12 u64.
+int cozk_spartan_second_round(cozk_ctx* ctx, const cozk_poly* z, const cozk_poly* a, const cozk_poly* b, const cozk_poly* c,
+                              const uint64_t coef[12], uint64_t out_a[12], uint64_t out_b[12]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && z && a && b && c && coef && out_a && out_b && a->mode == COZK_MODE_PLAIN && b->mode == COZK_MODE_PLAIN &&
+                         c->mode == COZK_MODE_PLAIN && z->len == a->len && z->len == b->len && z->len == c->len && z->len >= 2,
+                     "spartan_second_round: bad argument");
+        size_t half = z->len / 2;
+        unsigned gx = grid_capped(half);
+        if (gx > 512) gx = 512;
+        ctx->scratch.reserve((6 * (size_t)gx + 6) * sizeof(fe));
+        fe* partial = ctx->scratch.as<fe>();
+        fe* res = partial + 6 * (size_t)gx;
+        int nc = z->mode == COZK_MODE_REP3 ? 2 : 1;
+        fe c0 = fe_from_u64x4(coef), c1 = fe_from_u64x4(coef + 4), c2 = fe_from_u64x4(coef + 8);
+        if (nc == 2) k_spartan_second<2><<<gx, PT, 0, ctx->stream>>>(poly_a(z), poly_b(z), poly_a(a), poly_a(b), poly_a(c), c0, c1, c2, half, partial);
+        else k_spartan_second<1><<<gx, PT, 0, ctx->stream>>>(poly_a(z), nullptr, poly_a(a), poly_a(b), poly_a(c), c0, c1, c2, half, partial);
+        k_finish_sums<<<(unsigned)(3 * nc), PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        HIP_TRY(hipGetLastError());
+        fe h[6];
+        fetch_fe(ctx, res, (size_t)(3 * nc), h);
+        for (int e = 0; e < 3; e++) {
+            fe_to_u64x4(h[e], out_a + 4 * e);
+            if (nc == 2) fe_to_u64x4(h[3 + e], out_b + 4 * e);
+            else for (int k = 0; k < 4; k++) out_b[4 * e + k] = 0;
+        }
+    });
+}
+
+// SpartanProverWorker::zero_round (co-spartan/src/worker.rs:153-182): (za, zb, zc) = (A, B, C) . z on shares.
+// CSR: row_ptr (U32, nrows + 1), col (U32, nnz), val_a/b/c (FR, nnz).
+int cozk_sparse_matvec3(cozk_ctx* ctx, const cozk_vec* row_ptr, const cozk_vec* col, const cozk_vec* val_a, const cozk_vec* val_b,
+                        const cozk_vec* val_c, const cozk_poly* z, cozk_poly** out_za, cozk_poly** out_zb, cozk_poly** out_zc) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && row_ptr && col && val_a && val_b && val_c && z && out_za && out_zb && out_zc &&
+                         row_ptr->kind == COZK_SCALAR_U32 && col->kind == COZK_SCALAR_U32 && val_a->kind == COZK_SCALAR_FR &&
+                         val_b->kind == COZK_SCALAR_FR && val_c->kind == COZK_SCALAR_FR && row_ptr->n >= 2 &&
+                         val_a->n == col->n && val_b->n == col->n && val_c->n == col->n,
+                     "sparse_matvec3: bad argument");
+        size_t nrows = row_ptr->n - 1;
+        cozk_poly* o[3];
+        for (int i = 0; i < 3; i++) {
+            o[i] = new cozk_poly();
+            o[i]->ctx = ctx;
+            o[i]->mode = z->mode;
+            o[i]->len = o[i]->orig_len = nrows;
+            o[i]->cur = -1;
+            o[i]->own0 = true;
+            o[i]->a0 = dev_alloc_fe(nrows);
+            o[i]->b0 = z->mode == COZK_MODE_REP3 ? dev_alloc_fe(nrows) : nullptr;
+        }
+        if (z->mode == COZK_MODE_REP3)
+            k_sparse_matvec3<2><<<grid_for(nrows), PT, 0, ctx->stream>>>((const uint32_t*)row_ptr->d, (const uint32_t*)col->d, (const fe*)val_a->d, (const fe*)val_b->d,
+                                                                        (const fe*)val_c->d, poly_a(z), poly_b(z), nrows, o[0]->a0, o[0]->b0, o[1]->a0, o[1]->b0, o[2]->a0, o[2]->b0);
+        else
+            k_sparse_matvec3<1><<<grid_for(nrows), PT, 0, ctx->stream>>>((const uint32_t*)row_ptr->d, (const uint32_t*)col->d, (const fe*)val_a->d, (const fe*)val_b->d,
+                                                                        (const fe*)val_c->d, poly_a(z), nullptr, nrows, o[0]->a0, nullptr, o[1]->a0, nullptr, o[2]->a0, nullptr);
+        HIP_TRY(hipGetLastError());
+        *out_za = o[0];
+        *out_zb = o[1];
+        *out_zc = o[2];
     });
 }
 

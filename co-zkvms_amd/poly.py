@@ -299,3 +299,39 @@ class Rep3DenseInterleavedPolynomial:
             self.free()
         except Exception:
             pass
+
+
+def prod_sumcheck_evals(polys, degree):
+    """one round of prove_arbitrary_worker's evaluation loop for a product of polynomials
+    (co-jolt/src/subprotocols/sumcheck.rs:189-215): additive evaluations at x = 0, 2, .., degree"""
+    ctx = polys[0].ctx
+    out = np.zeros((degree, 4), dtype=np.uint64)
+    ctx.check(ctx._l.cozk_prod_sumcheck_evals(ctx.h, _ptr_array(polys), len(polys), degree, out.ctypes.data))
+    return mont_limbs_to_int(out)
+
+
+def spartan_first_round(za, zb, zc, pub):
+    """co-spartan first_sumcheck_prove_round evaluations at X = 0..3 (unmasked additive)"""
+    ctx = za.ctx
+    out = np.zeros((4, 4), dtype=np.uint64)
+    ctx.check(ctx._l.cozk_spartan_first_round(ctx.h, za.h, zb.h, zc.h, pub.h, out.ctypes.data))
+    return mont_limbs_to_int(out)
+
+
+def spartan_second_round(z, a, b, c, coef):
+    """co-spartan second_sumcheck_prove_round Rep3 evaluations at X = 0..2 (unmasked) -> [(a, b)] * 3"""
+    ctx = z.ctx
+    cf = fr_to_mont_limbs(coef)
+    oa = np.zeros((3, 4), dtype=np.uint64)
+    ob = np.zeros((3, 4), dtype=np.uint64)
+    ctx.check(ctx._l.cozk_spartan_second_round(ctx.h, z.h, a.h, b.h, c.h, cf.ctypes.data, oa.ctypes.data, ob.ctypes.data))
+    return list(zip(mont_limbs_to_int(oa), mont_limbs_to_int(ob)))
+
+
+def sparse_matvec3(row_ptr, col, val_a, val_b, val_c, z):
+    """co-spartan zero_round: (za, zb, zc) = (A, B, C) z on shares; CSR inputs are device Vecs"""
+    ctx = z.ctx
+    ha, hb, hc = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
+    ctx.check(ctx._l.cozk_sparse_matvec3(ctx.h, row_ptr.h, col.h, val_a.h, val_b.h, val_c.h, z.h, ctypes.byref(ha),
+                                         ctypes.byref(hb), ctypes.byref(hc)))
+    return Rep3DensePolynomial(ctx, ha), Rep3DensePolynomial(ctx, hb), Rep3DensePolynomial(ctx, hc)

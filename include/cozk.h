@@ -172,6 +172,28 @@ int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, c
  * out[2i] = eval_0, out[2i+1] = eval_2 (additive) */
 int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys,
                               const cozk_poly* const* eqs, size_t k, uint64_t* out);
+/* one round of prove_arbitrary_worker's evaluation loop (co-jolt/src/subprotocols/sumcheck.rs:189-215) for
+ * the comb_funcs the reference uses: a product of m <= 4 polynomials, at most one of them REP3 (Spartan
+ * inner / shift sumchecks r1cs/spartan/worker.rs:162-235; output check read_write_memory/worker.rs:149-164).
+ * out[e] = additive evaluation at x = 0, 2, .., degree; HighToLow (sumcheck_evals, dense_mlpoly.rs:113-147) */
+int cozk_prod_sumcheck_evals(cozk_ctx* ctx, const cozk_poly* const* polys, size_t m, int degree,
+                             uint64_t* out);
+/* co-noir-spartan: Rep3Sumcheck::first_sumcheck_prove_round evaluations at X = 0..3 of
+ * sum_b eq * (za x zb) - into_additive(zc * eq), before the additive zero-mask
+ * (co-noir-spartan/co-spartan/src/sumcheck.rs:171-280); fix_variables = cozk_poly_bind(.., LOW_TO_HIGH)
+ * on the SoA components (mpc-core/src/protocols/rep3/poly.rs:56-62) */
+int cozk_spartan_first_round(cozk_ctx* ctx, const cozk_poly* za, const cozk_poly* zb,
+                             const cozk_poly* zc, const cozk_poly* pub, uint64_t out[16]);
+/* Rep3Sumcheck::second_sumcheck_prove_round: Rep3 evaluations at X = 0..2 of
+ * sum_b z * (alpha A + beta B + gamma C), before the Rep3 mask (sumcheck.rs:282-395) */
+int cozk_spartan_second_round(cozk_ctx* ctx, const cozk_poly* z, const cozk_poly* a, const cozk_poly* b,
+                              const cozk_poly* c, const uint64_t coef[12], uint64_t out_a[12],
+                              uint64_t out_b[12]);
+/* SpartanProverWorker::zero_round (co-spartan/src/worker.rs:153-182): (za, zb, zc) = (A, B, C) z on shares;
+ * CSR rows: row_ptr (U32, nrows+1), col (U32, nnz), val_a/b/c (FR, nnz) */
+int cozk_sparse_matvec3(cozk_ctx* ctx, const cozk_vec* row_ptr, const cozk_vec* col,
+                        const cozk_vec* val_a, const cozk_vec* val_b, const cozk_vec* val_c,
+                        const cozk_poly* z, cozk_poly** out_za, cozk_poly** out_zb, cozk_poly** out_zc);
 /* one fold of PST13 `open` (pst13.rs:445-459): q[b] = r[2b+1]-r[2b]; r'[b] = r[2b](1-p) + r[2b+1]p */
 int cozk_pst_fold(cozk_ctx* ctx, const cozk_vec* r, const uint64_t p[4], cozk_vec* q, cozk_vec* r_next);
 

@@ -931,3 +931,71 @@ def synthetic_fr(seed, n, max_bits=0):
 
 def synthetic_small(seed, n, bits):
     return [SplitMix64((seed + i * _STREAM_MUL) & 0xFFFFFFFFFFFFFFFF).next() & ((1 << bits) - 1) for i in range(n)]
+
+
+# --------------------------------------------------------------------------------------------
+# generic product sumcheck (prove_arbitrary_worker) and co-noir-spartan rounds
+# --------------------------------------------------------------------------------------------
+def prod_round_evals(polys, degree):
+    """co-jolt/src/subprotocols/sumcheck.rs:189-215 with comb_func = product of the polynomials' evaluations
+    (at most one shared factor): sum over i of prod_j sumcheck_evals(P_j, i, degree, HighToLow)[e];
+    points 0, 2, 3, .., degree.  Shared x public = mul_public then into_additive."""
+    half = len(polys[0]) // 2
+    acc = [0] * degree
+    for i in range(half):
+        evs = [dense_sumcheck_evals(p, i, degree, HIGH_TO_LOW) for p in polys]
+        for e in range(degree):
+            prod = None
+            for ev in evs:
+                v = ev[e]
+                if prod is None:
+                    prod = v
+                elif isinstance(prod, tuple):
+                    prod = rep3_mul_public(prod, v)
+                elif isinstance(v, tuple):
+                    prod = rep3_mul_public(v, prod)
+                else:
+                    prod = prod * v % R
+            acc[e] = (acc[e] + sh_into_additive(prod)) % R
+    return acc
+
+
+def spartan_first_round_evals(za, zb, zc, pub):
+    """co-noir-spartan/co-spartan/src/sumcheck.rs:171-280 (before the additive mask): X = 0..3"""
+    half = len(pub) // 2
+    out = [0, 0, 0, 0]
+    for b in range(half):
+        a0, b0, c0, p0 = za[2 * b], zb[2 * b], zc[2 * b], pub[2 * b]
+        sa, sb, sc = sh_sub(za[2 * b + 1], a0), sh_sub(zb[2 * b + 1], b0), sh_sub(zc[2 * b + 1], c0)
+        sp = (pub[2 * b + 1] - p0) % R
+        for t in range(4):
+            term = sh_local_mul(a0, b0) * p0 - sh_into_additive(sh_mul_public(c0, p0))
+            out[t] = (out[t] + term) % R
+            a0, b0, c0, p0 = sh_add(a0, sa), sh_add(b0, sb), sh_add(c0, sc), (p0 + sp) % R
+    return out
+
+
+def spartan_second_round_evals(z, pa, pb, pc, coef):
+    """co-noir-spartan/co-spartan/src/sumcheck.rs:282-395 (before the Rep3 mask): X = 0..2, share-valued"""
+    half = len(pa) // 2
+    out = [sh_zero(z[0])] * 3
+    out = list(out)
+    for b in range(half):
+        z0 = z[2 * b]
+        sz = sh_sub(z[2 * b + 1], z0)
+        a0, b0, c0 = pa[2 * b], pb[2 * b], pc[2 * b]
+        sa, sb, sc = (pa[2 * b + 1] - a0) % R, (pb[2 * b + 1] - b0) % R, (pc[2 * b + 1] - c0) % R
+        for t in range(3):
+            lin = (a0 * coef[0] + b0 * coef[1] + c0 * coef[2]) % R
+            out[t] = sh_add(out[t], sh_mul_public(z0, lin))
+            z0, a0, b0, c0 = sh_add(z0, sz), (a0 + sa) % R, (b0 + sb) % R, (c0 + sc) % R
+    return out
+
+
+def sparse_matvec(entries, z, nrows):
+    """co-noir-spartan/co-spartan/src/worker.rs:153-182: out[row] += z[col] * val for (row, col, val) in entries"""
+    out = [sh_zero(z[0])] * nrows
+    out = list(out)
+    for row, col, val in entries:
+        out[row] = sh_add(out[row], sh_mul_public(z[col], val))
+    return out
