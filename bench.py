@@ -101,6 +101,17 @@ def main():
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                 "launches": prof["launches"], "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_per_launch),
                 "kernel_share_of_step": round(prof["total_ms"] / (dt * 1e3), 4)}
+    # HBM traffic of the dominant kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE,
+    # separate runs; profiles/r1_pmc_hbm.json).  bench.py cannot run rocprofv3 on itself, so this is the
+    # per-launch average of the same command at the same sizes, reported only when sizes match the default.
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_msm_accum0"]
+        if log_n == 20:
+            roofline["traffic"] = int((pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024)
+            roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch, raw (uncalibrated for 64-B gathers); ~10x the algorithmic bytes "
+                                        "because every bucket method reads a base once per window: 16 windows x 64 B per scalar")
+    except Exception:
+        pass
     # the honest ceiling of this kernel is the integer ALU: measured Fq mont-mul peak
     ctx = pkg.Context(dev)
     lanes = 256 * 256 * 16
