@@ -699,3 +699,84 @@ cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party) {
 }
 
 }  // extern "C"
+
+// --------------------------------------------------------------------------- worker drivers over host nets
+// The C++ round loops of csrc/host/prover.hpp with the host's own transport plugged in (cozk_star_net /
+// cozk_ring_net): what a Rust host calls when it wants the loop, not just the per-round kernels.
+static WorkerEnv make_env(cozk_ctx* ctx, const cozk_worker_params* wp, StarNetWorker* star, RingNet* ring) {
+    WorkerEnv env;
+    env.ctx = ctx;
+    env.mode = wp->mode;
+    env.party = wp->party;
+    env.star = star;
+    env.ring = ring;
+    env.seed_self = wp->seed_self;
+    env.seed_prev = wp->seed_prev;
+    env.mask_ctr = wp->mask_counter;
+    return env;
+}
+static void copy_out_fr(const std::vector<fe>& v, uint64_t* out, size_t cap, size_t* n_out, const char* what) {
+    if (n_out) *n_out = v.size();
+    if (!out) return;
+    if (v.size() > cap) throw CozkError(COZK_ERR_INVALID_ARG, std::string(what) + ": output buffer too small");
+    for (size_t i = 0; i < v.size(); i++) fe_to_u64x4(v[i], out + 4 * i);
+}
+
+extern "C" {
+
+int cozk_worker_prove_grand_product(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star, const cozk_ring_net* ring,
+                                    cozk_layer* leaves, size_t batch_size, uint64_t* out_r, size_t r_cap, size_t* out_r_len) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && wp && star && leaves && (wp->mode == COZK_MODE_PLAIN || ring), "worker_prove_grand_product: bad argument");
+        CallbackStarWorker sw(*star);
+        std::unique_ptr<CallbackRingNet> rn(ring ? new CallbackRingNet(*ring) : nullptr);
+        WorkerEnv env = make_env(ctx, wp, &sw, rn.get());
+        cozk_layer* lv = nullptr;
+        rc_check(cozk_layer_clone(ctx, leaves, &lv), ctx, "layer_clone");
+        Rep3BatchedDenseGrandProduct gp = Rep3BatchedDenseGrandProduct::construct(env, LayerH(lv), batch_size);
+        std::vector<fe> r = gp.prove_grand_product_worker(env);
+        copy_out_fr(r, out_r, r_cap, out_r_len, "worker_prove_grand_product");
+    });
+}
+
+int cozk_worker_prove_arbitrary(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star, cozk_poly* const* polys, size_t m,
+                                int combined_degree, const uint64_t claim[4], int num_rounds, uint64_t* out_r, uint64_t* out_final_evals) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && wp && star && polys && claim && m >= 1, "worker_prove_arbitrary: bad argument");
+        CallbackStarWorker sw(*star);
+        WorkerEnv env = make_env(ctx, wp, &sw, nullptr);
+        std::vector<cozk_poly*> ps(polys, polys + m);
+        ArbitraryResult res = prove_arbitrary_worker(env, fe_from_u64x4(claim), num_rounds, ps, combined_degree);
+        copy_out_fr(res.r, out_r, (size_t)num_rounds, nullptr, "worker_prove_arbitrary");
+        copy_out_fr(res.final_evals, out_final_evals, m, nullptr, "worker_prove_arbitrary");
+    });
+}
+
+int cozk_worker_spartan_first_sumcheck(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star, cozk_poly* za, cozk_poly* zb,
+                                       cozk_poly* zc, cozk_poly* eq, uint64_t* out_point, uint64_t out_finals[16]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && wp && star && za && zb && zc && eq, "worker_spartan_first_sumcheck: bad argument");
+        CallbackStarWorker sw(*star);
+        WorkerEnv env = make_env(ctx, wp, &sw, nullptr);
+        std::vector<fe> finals;
+        std::vector<fe> pt = rep3_first_sumcheck_worker(env, za, zb, zc, eq, finals);
+        copy_out_fr(pt, out_point, pt.size(), nullptr, "spartan_first");
+        copy_out_fr(finals, out_finals, 4, nullptr, "spartan_first");
+    });
+}
+
+int cozk_worker_spartan_second_sumcheck(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star, cozk_poly* z, cozk_poly* a,
+                                        cozk_poly* b, cozk_poly* c, const uint64_t coef[12], uint64_t* out_point, uint64_t out_finals[16]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && wp && star && z && a && b && c && coef, "worker_spartan_second_sumcheck: bad argument");
+        CallbackStarWorker sw(*star);
+        WorkerEnv env = make_env(ctx, wp, &sw, nullptr);
+        fe cf[3] = {fe_from_u64x4(coef), fe_from_u64x4(coef + 4), fe_from_u64x4(coef + 8)};
+        std::vector<fe> finals;
+        std::vector<fe> pt = rep3_second_sumcheck_worker(env, z, a, b, c, cf, finals);
+        copy_out_fr(pt, out_point, pt.size(), nullptr, "spartan_second");
+        copy_out_fr(finals, out_finals, 4, nullptr, "spartan_second");
+    });
+}
+
+}  // extern "C"

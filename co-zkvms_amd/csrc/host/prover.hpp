@@ -825,4 +825,167 @@ struct Rep3ProverOpeningAccumulator {
     }
 };
 
+// ================================================================= generic sumcheck (prove_arbitrary_worker)
+// co-jolt/src/subprotocols/sumcheck.rs:168-246 for comb_func = product of the polynomials (at most one shared
+// factor; Spartan inner/shift sumchecks r1cs/spartan/worker.rs:162-235, output check read_write_memory/worker.rs:149-164).
+// Binds HighToLow; returns r and the polynomials' final claims as additive shares.
+struct ArbitraryResult {
+    std::vector<fe> r;
+    std::vector<fe> final_evals;
+};
+static ArbitraryResult prove_arbitrary_worker(WorkerEnv& env, const fe& claim, int num_rounds, std::vector<cozk_poly*>& polys,
+                                              int combined_degree) {
+    COZK_REQUIRE(combined_degree >= 1 && combined_degree <= 3 && !polys.empty() && polys.size() <= 4, "prove_arbitrary: unsupported shape");
+    ArbitraryResult res;
+    fe previous_claim = claim;
+    bool any_shared = false;
+    for (auto* p : polys) any_shared |= cozk_poly_mode(p) == COZK_MODE_REP3;
+    for (int round = 0; round < num_rounds; round++) {
+        std::vector<uint64_t> ev(4 * (size_t)combined_degree);
+        rc_check(cozk_prod_sumcheck_evals(env.ctx, polys.data(), polys.size(), combined_degree, ev.data()), env.ctx, "prod_sumcheck_evals");
+        std::vector<fe> pts((size_t)combined_degree + 1);
+        for (int e = 0; e < combined_degree; e++) {
+            fe v = fe_from_u64x4(ev.data() + 4 * e);
+            // a product of public polynomials is a public value: additive share held by P0 only
+            if (!any_shared && env.mode == COZK_MODE_REP3) v = env.additive_trivial(v);
+            pts[e == 0 ? 0 : e + 1] = v;
+        }
+        pts[1] = Fr::sub(previous_claim, pts[0]);  // eval_points.insert(1, previous_claim - eval_points[0])
+        std::vector<fe> cf((size_t)combined_degree + 1);
+        if (combined_degree == 1) {
+            cf[0] = pts[0];
+            cf[1] = Fr::sub(pts[1], pts[0]);
+        } else {
+            unipoly_from_evals(pts.data(), combined_degree + 1, cf.data());
+        }
+        Writer w;
+        w.vec_fr(cf);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r_j = rd.fr();
+        fe next_claim = rd.fr();
+        res.r.push_back(r_j);
+        uint64_t rr[4];
+        fe_to_u64x4(r_j, rr);
+        for (auto* p : polys) rc_check(cozk_poly_bind(env.ctx, p, rr, COZK_HIGH_TO_LOW), env.ctx, "bind");
+        previous_claim = env.additive_trivial(next_claim);
+    }
+    for (auto* p : polys) {
+        uint64_t a[4], b[4] = {0, 0, 0, 0};
+        rc_check(cozk_poly_get_coeff(env.ctx, p, 0, a, b), env.ctx, "get_coeff");
+        if (cozk_poly_mode(p) == COZK_MODE_REP3) res.final_evals.push_back(env.into_additive(Share{fe_from_u64x4(a), fe_from_u64x4(b)}));
+        else res.final_evals.push_back(env.mode == COZK_MODE_REP3 ? env.additive_trivial(fe_from_u64x4(a)) : fe_from_u64x4(a));
+    }
+    return res;
+}
+
+// ================================================================= co-noir-spartan sumcheck workers
+// rep3_first_sumcheck_worker (co-noir-spartan/co-spartan/src/worker.rs:593-639): per round send the 4
+// evaluations (+ additive zero-mask, co-spartan/src/sumcheck.rs:271-273), receive r, fix_variables.
+// The mask stream is PRF(seed_self) - PRF(seed_prev) (get_mask_scalar_additive, mpc-core/src/protocols/additive.rs:44-50);
+// returns the point; `finals` = (za, zb, zc share_0[0], eq[0]) as sent at the end.
+static fe spartan_mask_additive(WorkerEnv& env);
+static std::vector<fe> rep3_first_sumcheck_worker(WorkerEnv& env, cozk_poly* za, cozk_poly* zb, cozk_poly* zc, cozk_poly* eq, std::vector<fe>& finals) {
+    size_t len = cozk_poly_len(eq);
+    int num_vars = 0;
+    while (((size_t)1 << num_vars) < len) num_vars++;
+    std::vector<fe> point;
+    for (int round = 0; round < num_vars; round++) {
+        uint64_t ev[16];
+        rc_check(cozk_spartan_first_round(env.ctx, za, zb, zc, eq, ev), env.ctx, "spartan_first_round");
+        std::vector<fe> msg(4);
+        for (int t = 0; t < 4; t++) msg[t] = Fr::add(fe_from_u64x4(ev + 4 * t), spartan_mask_additive(env));
+        Writer w;
+        w.vec_fr(msg);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r = rd.fr();
+        point.push_back(r);
+        uint64_t rr[4];
+        fe_to_u64x4(r, rr);
+        for (cozk_poly* p : {za, zb, zc, eq}) rc_check(cozk_poly_bind(env.ctx, p, rr, COZK_LOW_TO_HIGH), env.ctx, "fix_variables");
+    }
+    finals.clear();
+    Writer w;
+    for (cozk_poly* p : {za, zb, zc, eq}) {
+        uint64_t a[4], b[4];
+        rc_check(cozk_poly_get_coeff(env.ctx, p, 0, a, b), env.ctx, "get_coeff");
+        finals.push_back(fe_from_u64x4(a));
+        w.fr(finals.back());
+    }
+    env.star->send_response(w.b);
+    return point;
+}
+
+// rep3_second_sumcheck_worker (co-spartan/src/sumcheck.rs:282-395 round function): 3 Rep3 evaluations per round
+static std::vector<fe> rep3_second_sumcheck_worker(WorkerEnv& env, cozk_poly* z, cozk_poly* a, cozk_poly* b, cozk_poly* c, const fe coef[3],
+                                                   std::vector<fe>& finals) {
+    size_t len = cozk_poly_len(z);
+    int num_vars = 0;
+    while (((size_t)1 << num_vars) < len) num_vars++;
+    uint64_t cf[12];
+    for (int i = 0; i < 3; i++) fe_to_u64x4(coef[i], cf + 4 * i);
+    std::vector<fe> point;
+    for (int round = 0; round < num_vars; round++) {
+        uint64_t ea[12], eb[12];
+        rc_check(cozk_spartan_second_round(env.ctx, z, a, b, c, cf, ea, eb), env.ctx, "spartan_second_round");
+        Writer w;
+        w.u64(3);
+        for (int t = 0; t < 3; t++) {
+            // get_mask_scalar_rep3 (mpc-core/src/protocols/rep3/arithmetic.rs:39-48): a zero-sharing per component
+            fe m0 = spartan_mask_additive(env), m1 = spartan_mask_additive(env);
+            w.fr(Fr::add(fe_from_u64x4(ea + 4 * t), m0));
+            w.fr(env.mode == COZK_MODE_REP3 ? Fr::add(fe_from_u64x4(eb + 4 * t), m1) : Fr::zero());
+        }
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r = rd.fr();
+        point.push_back(r);
+        uint64_t rr[4];
+        fe_to_u64x4(r, rr);
+        for (cozk_poly* p : {z, a, b, c}) rc_check(cozk_poly_bind(env.ctx, p, rr, COZK_LOW_TO_HIGH), env.ctx, "fix_variables");
+    }
+    finals.clear();
+    Writer w;
+    for (cozk_poly* p : {z, a, b, c}) {
+        uint64_t x[4], y[4];
+        rc_check(cozk_poly_get_coeff(env.ctx, p, 0, x, y), env.ctx, "get_coeff");
+        finals.push_back(fe_from_u64x4(x));
+        w.fr(finals.back());
+    }
+    env.star->send_response(w.b);
+    return point;
+}
+
+// host-side PRF for the tiny per-round masks: the same SplitMix64 stream as the device PRF (poly.hip prf_fr)
+static inline uint64_t host_sm_next(uint64_t& s) {
+    s += 0x9E3779B97F4A7C15ull;
+    uint64_t z = s;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+static inline fe host_prf_fr(uint64_t seed, uint64_t j) {
+    uint64_t s = seed + j * 0xD1342543DE82EF95ull;
+    fe v;
+    for (;;) {
+        uint64_t w0 = host_sm_next(s), w1 = host_sm_next(s), w2 = host_sm_next(s), w3 = host_sm_next(s) & ((1ull << 62) - 1ull);
+        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
+        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
+        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
+        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
+        if (!Fr::geq_mod(v)) break;
+    }
+    return Fr::to_mont(v);
+}
+static fe spartan_mask_additive(WorkerEnv& env) {
+    if (env.mode != COZK_MODE_REP3) return Fr::zero();  // a single party has nothing to hide from itself
+    fe m = Fr::sub(host_prf_fr(env.seed_self, env.mask_ctr), host_prf_fr(env.seed_prev, env.mask_ctr));
+    env.mask_ctr++;
+    return m;
+}
+
 }  // namespace cozk

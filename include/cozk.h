@@ -250,6 +250,35 @@ typedef struct cozk_ring_net {
     int (*reshare)(void* user, const void* dev_send, void* dev_recv, size_t nbytes);
 } cozk_ring_net;
 
+/* ---------------------------------------------------------------- worker drivers ----------- */
+/* The C++ round loops (csrc/host/prover.hpp) run against host-supplied nets: the calls a Rust host makes
+ * when it wants the whole loop rather than the per-round kernels. */
+typedef struct cozk_worker_params {
+    int mode;               /* COZK_MODE_PLAIN / COZK_MODE_REP3 */
+    int party;              /* PartyID 0..2 */
+    uint64_t seed_self;     /* zero-sharing PRF key shared with the next party */
+    uint64_t seed_prev;     /* ... with the previous party */
+    uint64_t mask_counter;  /* starting counter of the zero-sharing stream */
+} cozk_worker_params;
+/* construct + prove_grand_product_worker (co-jolt/src/subprotocols/grand_product.rs:111-130,239-255) on a
+ * clone of `leaves`; ring may be NULL for the plain prover.  out_r = final point (r_cap x 4 u64). */
+int cozk_worker_prove_grand_product(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star,
+                                    const cozk_ring_net* ring, cozk_layer* leaves, size_t batch_size,
+                                    uint64_t* out_r, size_t r_cap, size_t* out_r_len);
+/* prove_arbitrary_worker (co-jolt/src/subprotocols/sumcheck.rs:168-246), comb_func = product of the m
+ * polynomials; binds them HighToLow in place; out_r = num_rounds x 4, out_final_evals = m x 4 (additive) */
+int cozk_worker_prove_arbitrary(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star,
+                                cozk_poly* const* polys, size_t m, int combined_degree,
+                                const uint64_t claim[4], int num_rounds, uint64_t* out_r,
+                                uint64_t* out_final_evals);
+/* rep3_first_sumcheck_worker / second (co-noir-spartan/co-spartan/src/worker.rs:593-639, sumcheck.rs:171-395) */
+int cozk_worker_spartan_first_sumcheck(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star,
+                                       cozk_poly* za, cozk_poly* zb, cozk_poly* zc, cozk_poly* eq,
+                                       uint64_t* out_point, uint64_t out_finals[16]);
+int cozk_worker_spartan_second_sumcheck(cozk_ctx* ctx, const cozk_worker_params* wp, const cozk_star_net* star,
+                                        cozk_poly* z, cozk_poly* a, cozk_poly* b, cozk_poly* c,
+                                        const uint64_t coef[12], uint64_t* out_point, uint64_t out_finals[16]);
+
 /* ---------------------------------------------------------------- in-process harness ------- */
 /* Counterpart of the reference's runner (co-jolt/examples/rep3_jolt.rs:118-317, run_3_party_jolt.sh):
  * synthesises one trace's witness, runs every party on its own thread / ctx and the

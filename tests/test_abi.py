@@ -24,7 +24,8 @@ def test_header_symbols_exported(cozk):
     # every symbol the python layer binds is declared in the header
     from importlib import import_module
     hp = import_module("co-zkvms_amd.harness")
-    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS:
+    wk = import_module("co-zkvms_amd.workers")
+    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS + wk.WORKER_SYMBOLS:
         assert n in names, n
 
 
