@@ -17,8 +17,12 @@ class Group:
         self.torch = torch
         self.dist = dist
         self.rank, self.local_rank, self.world = env_world()
-        self.cuda = device is not None
+        # COZK_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box): the tiny
+        # collectives then run on CPU tensors while the proving still happens on the GPU
+        backend = backend or os.environ.get("COZK_DIST_BACKEND") or None
         self.device = device
+        self.cuda = device is not None and backend != "gloo"
+        self.sync_device = device
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
@@ -28,8 +32,8 @@ class Group:
         return self.torch.device("cuda", self.device) if self.cuda else self.torch.device("cpu")
 
     def barrier(self):
-        if self.cuda:
-            self.torch.cuda.synchronize(self.device)
+        if self.sync_device is not None:
+            self.torch.cuda.synchronize(self.sync_device)
         if self.world > 1:
             # an all_reduce on the rank's own device doubles as the barrier (works for nccl and gloo)
             t = self.torch.zeros(1, device=self._dev())

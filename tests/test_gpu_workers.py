@@ -27,7 +27,12 @@ def test_prove_arbitrary_worker_callbacks(cozk, ctx, degree, m):
     n = 128
     ref = [[rng.field() for _ in range(n)] for _ in range(m)]
     polys = [cozk.Rep3DensePolynomial.new(ctx, c) for c in ref]
-    claim = sum(eval("*".join(f"ref[{j}][i]" for j in range(m))) for i in range(n)) % O.R
+    claim = 0
+    for i in range(n):
+        t = 1
+        for j in range(m):
+            t = t * ref[j][i] % O.R
+        claim = (claim + t) % O.R
     state = {"ref": ref, "claim": claim, "msgs": 0, "pending": None}
 
     def on_send(b):
