@@ -80,50 +80,55 @@ struct G1 {
         r.zzz = Fq::mul(W, p.zzz);
         return r;
     }
-    // P + Q, Q affine (EFD madd-2008-s)
+    // P + Q, Q affine (EFD madd-2008-s).  The ten products are issued as five independent pairs (mul2).
     static FF_HD g1_xyzz add_mixed(const g1_xyzz& p, const g1_affine& q) {
         if (is_inf(q)) return p;
         if (is_identity(p)) return from_affine(q);
-        fe U2 = Fq::mul(q.x, p.zz);
-        fe S2 = Fq::mul(q.y, p.zzz);
+        fe U2, S2;
+        Fq::mul2(q.x, p.zz, q.y, p.zzz, U2, S2);
         fe Pd = Fq::sub(U2, p.x);
         fe Rd = Fq::sub(S2, p.y);
         if (Fq::is_zero(Pd)) {
             if (Fq::is_zero(Rd)) return dbl_affine(q);
             return identity();
         }
-        fe PP = Fq::sqr(Pd);
-        fe PPP = Fq::mul(Pd, PP);
-        fe Q = Fq::mul(p.x, PP);
+        fe PP, RR;
+        Fq::mul2(Pd, Pd, Rd, Rd, PP, RR);
+        fe PPP, Q;
+        Fq::mul2(Pd, PP, p.x, PP, PPP, Q);
         g1_xyzz r;
-        r.x = Fq::sub(Fq::sub(Fq::sqr(Rd), PPP), Fq::dbl(Q));
-        r.y = Fq::sub(Fq::mul(Rd, Fq::sub(Q, r.x)), Fq::mul(p.y, PPP));
-        r.zz = Fq::mul(p.zz, PP);
-        r.zzz = Fq::mul(p.zzz, PPP);
+        r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
+        fe t1, t2;
+        Fq::mul2(Rd, Fq::sub(Q, r.x), p.y, PPP, t1, t2);
+        r.y = Fq::sub(t1, t2);
+        Fq::mul2(p.zz, PP, p.zzz, PPP, r.zz, r.zzz);
         return r;
     }
-    // P + Q (EFD add-2008-s)
+    // P + Q (EFD add-2008-s): 14 products as seven independent pairs
     static FF_HD g1_xyzz add(const g1_xyzz& p, const g1_xyzz& q) {
         if (is_identity(q)) return p;
         if (is_identity(p)) return q;
-        fe U1 = Fq::mul(p.x, q.zz);
-        fe U2 = Fq::mul(q.x, p.zz);
-        fe S1 = Fq::mul(p.y, q.zzz);
-        fe S2 = Fq::mul(q.y, p.zzz);
+        fe U1, U2, S1, S2;
+        Fq::mul2(p.x, q.zz, q.x, p.zz, U1, U2);
+        Fq::mul2(p.y, q.zzz, q.y, p.zzz, S1, S2);
         fe Pd = Fq::sub(U2, U1);
         fe Rd = Fq::sub(S2, S1);
         if (Fq::is_zero(Pd)) {
             if (Fq::is_zero(Rd)) return dbl(p);
             return identity();
         }
-        fe PP = Fq::sqr(Pd);
-        fe PPP = Fq::mul(Pd, PP);
-        fe Q = Fq::mul(U1, PP);
+        fe PP, RR;
+        Fq::mul2(Pd, Pd, Rd, Rd, PP, RR);
+        fe PPP, Q;
+        Fq::mul2(Pd, PP, U1, PP, PPP, Q);
         g1_xyzz r;
-        r.x = Fq::sub(Fq::sub(Fq::sqr(Rd), PPP), Fq::dbl(Q));
-        r.y = Fq::sub(Fq::mul(Rd, Fq::sub(Q, r.x)), Fq::mul(S1, PPP));
-        r.zz = Fq::mul(Fq::mul(p.zz, q.zz), PP);
-        r.zzz = Fq::mul(Fq::mul(p.zzz, q.zzz), PPP);
+        r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
+        fe t1, t2;
+        Fq::mul2(Rd, Fq::sub(Q, r.x), S1, PPP, t1, t2);
+        r.y = Fq::sub(t1, t2);
+        fe zz12, zzz12;
+        Fq::mul2(p.zz, q.zz, p.zzz, q.zzz, zz12, zzz12);
+        Fq::mul2(zz12, PP, zzz12, PPP, r.zz, r.zzz);
         return r;
     }
     // affine = (X/ZZ, Y/ZZZ); one field inversion: 1/ZZZ, then 1/ZZ = ZZ^2 / ZZZ^2 ... computed as

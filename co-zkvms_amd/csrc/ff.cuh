@@ -15,6 +15,7 @@
 #define FF_HD __host__ __device__ __forceinline__
 #if defined(__HIP_DEVICE_COMPILE__)
 #include "ff_macc.inc"
+#include "ff_mul2.inc"
 #endif
 
 struct alignas(16) fe {
@@ -223,6 +224,33 @@ struct Field {
 #endif
     }
     static FF_HD fe sqr(const fe& a) { return mul(a, a); }
+
+    // Two independent products r1 = a*b, r2 = c*d.  On the device their column-accumulator chains are
+    // interleaved instruction by instruction (ff_mul2.inc): at the 4 waves/SIMD the EC kernels run at, one
+    // chain per wave reaches ~105 G mul/s while two interleaved chains reach the ~128 G mul/s peak.
+    static FF_HD void mul2(const fe& a, const fe& b, const fe& c, const fe& d, fe& o1, fe& o2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t lo1 = 0, lo2 = 0;
+        uint32_t hi1 = 0, hi2 = 0;
+        uint32_t m1[8], m2[8], r1[8], r2[8];
+        const uint32_t* A = a.l;
+        const uint32_t* B = b.l;
+        const uint32_t* C = c.l;
+        const uint32_t* D = d.l;
+        FF_MUL2_BODY
+        fe t1, t2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            t1.l[i] = r1[i];
+            t2.l[i] = r2[i];
+        }
+        o1 = reduce_once(t1);
+        o2 = reduce_once(t2);
+#else
+        o1 = mul(a, b);
+        o2 = mul(c, d);
+#endif
+    }
 
     static FF_HD fe to_mont(const fe& a) { return mul(a, r2()); }
     static FF_HD fe from_mont(const fe& a) {

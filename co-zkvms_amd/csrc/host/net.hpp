@@ -14,6 +14,7 @@
 #include <condition_variable>
 #include <deque>
 #include <mutex>
+#include <thread>
 
 #include "wire.hpp"
 
@@ -62,6 +63,20 @@ struct Chan {
         cv.notify_all();
     }
     T pop() {
+        // a sumcheck round is a ~50 us ping-pong between a worker and the coordinator: spin briefly
+        // before paying a futex sleep/wake-up on every message
+        for (int spin = 0; spin < 2000; spin++) {
+            {
+                std::lock_guard<std::mutex> g(m);
+                if (!q.empty()) {
+                    T v = std::move(q.front());
+                    q.pop_front();
+                    return v;
+                }
+            }
+            if (abort && abort->flag.load()) throw CozkError(COZK_ERR_INTERNAL, "aborted: a peer failed");
+            std::this_thread::yield();
+        }
         std::unique_lock<std::mutex> g(m);
         while (q.empty()) {
             if (abort && abort->flag.load()) throw CozkError(COZK_ERR_INTERNAL, "aborted: a peer failed");

@@ -483,10 +483,14 @@ static fe* dev_alloc_fe(size_t n) {
 // copy k small results from device scratch to host (sync)
 static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
     fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
-    HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    // round results are written by the finishing kernel straight into pinned (device-visible) host memory:
+    // then there is nothing to copy, only the stream to drain
+    if (d != pin) HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < k; i++) h[i] = pin[i];
 }
+// where a finishing kernel should put k round results (pinned host memory, mapped into the device)
+static fe* result_slot(cozk_ctx* ctx, size_t k) { return (fe*)ctx_pinned(ctx, k * sizeof(fe)); }
 
 // build an eq table on device: out (len 2^nv) from point r (host), big-endian
 static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp) {
@@ -819,7 +823,7 @@ int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys, cons
         const fe** de = db + k;
         size_t* dh = (size_t*)(de + k);
         fe* partial = (fe*)(((uintptr_t)(dh + k) + 31) & ~(uintptr_t)31);
-        fe* res = partial + 2 * k * gx;
+        fe* res = result_slot(ctx, 2 * k);
         HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(de, he.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
@@ -1173,7 +1177,7 @@ int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
         if (gx > 1024) gx = 1024;
         ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
         fe* partial = ctx->scratch.as<fe>();
-        fe* res = partial + 3 * (size_t)gx;
+        fe* res = result_slot(ctx, 3);
         const fe* a = l->buf[l->cur][0];
         const fe* b = l->buf[l->cur][1];
         const fe* E1 = eq->E1[eq->c1];
