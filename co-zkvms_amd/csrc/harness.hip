@@ -112,6 +112,7 @@ double now_ms() {
 
 struct cozk_harness {
     cozk_harness_config cfg;
+    int local_party = -1;  // >= 0: distributed form, only this party lives in this process
     int nparties = 1;
     size_t N = 0;
     std::vector<PartyState> parties;
@@ -543,7 +544,8 @@ static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundl
         joint_claim = Fr::add(joint_claim, Fr::mul(gp_pw[i], Fr::mul(sc, proof.reduced.sumcheck_claims[i])));
     }
     std::vector<fe> rev(rs.rbegin(), rs.rend());
-    if (!PST13::check_with_trapdoor(*h->parties[0].setup, joint_c, rev, joint_claim, proof.reduced.joint_opening_proof)) {
+    const PST13Setup& vsetup = *h->parties[h->local_party >= 0 ? h->local_party : 0].setup;  // same SRS everywhere
+    if (!PST13::check_with_trapdoor(vsetup, joint_c, rev, joint_claim, proof.reduced.joint_opening_proof)) {
         why = "PST13 opening check failed";
         return 0;
     }
@@ -683,6 +685,153 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
     s.update(h->last_proof.data(), h->last_proof.size());
     s.final(res->proof_digest);
     return COZK_OK;
+}
+
+// ---- distributed form: ONE party per process / GPU (BASELINE config 3: "one MI355X per party").
+// Every process runs its own copy of the (deterministic) coordinator: a "star" gather is an all-gather of
+// the parties' messages through the host's transport (`cozk_hub_net`, e.g. torch.distributed / RCCL), after
+// which each copy derives the same challenge -- no coordinator process, no extra hop.  The ring reshare goes
+// through `cozk_ring_net` on device pointers (an RCCL send/recv pair over xGMI).
+int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, cozk_harness** out) {
+    if (!cfg || !out) return COZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    cozk_harness* h = new cozk_harness();
+    h->cfg = *cfg;
+    try {
+        COZK_REQUIRE(cfg->mode == COZK_MODE_REP3 && local_party >= 0 && local_party < 3, "harness_create_party: REP3 with party 0..2");
+        COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24 && cfg->gp_batch >= 1 && cfg->gp_log_leaves >= 1, "harness: bad shape");
+        int gbits = 0;
+        while ((1 << gbits) < cfg->gp_batch) gbits++;
+        COZK_REQUIRE(gbits + cfg->gp_log_leaves >= cfg->log_n, "harness: grand-product point shorter than the opening point");
+        h->nparties = 3;
+        h->local_party = local_party;
+        h->N = (size_t)1 << cfg->log_n;
+        h->parties.resize(3);
+        for (int p = 0; p < 3; p++) h->parties[p].party = p;
+        PartyState& ps = h->parties[local_party];
+        int rc = cozk_ctx_create(cfg->devices[local_party], &ps.ctx);
+        if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
+        ps.own_ctx = true;
+        HIP_TRY(hipSetDevice(ps.ctx->device));
+        setup_party(h, ps);
+    } catch (const CozkError& e) {
+        h->error = e.what();
+        *out = h;
+        return e.code;
+    } catch (const std::exception& e) {
+        h->error = e.what();
+        *out = h;
+        return COZK_ERR_INTERNAL;
+    }
+    *out = h;
+    return COZK_OK;
+}
+
+namespace {
+struct HubStarCoordinator : StarNetCoordinator {
+    InProcStar* local;  // only slot `me` is used: the local worker's up/down channels
+    cozk_hub_net hub;
+    int me;
+    HubStarCoordinator(InProcStar* l, const cozk_hub_net& h, int me_) : local(l), hub(h), me(me_) {}
+    std::vector<Bytes> gather(const Bytes& mine) {
+        const size_t cap = 1 << 18;
+        std::vector<uint8_t> recv((size_t)hub.n_participants * cap);
+        std::vector<size_t> lens((size_t)hub.n_participants, 0);
+        if (mine.size() > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: message larger than the 256 KiB slot");
+        if (hub.all_gather(hub.user, mine.data(), mine.size(), recv.data(), cap, lens.data()) != 0)
+            throw CozkError(COZK_ERR_INTERNAL, "hub all_gather callback failed");
+        std::vector<Bytes> out;
+        for (int p = 0; p < hub.n_participants; p++) {
+            if (lens[p] > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: bad length");
+            out.emplace_back(recv.begin() + (size_t)p * cap, recv.begin() + (size_t)p * cap + lens[p]);
+        }
+        return out;
+    }
+    int n_workers() const override { return hub.n_participants; }
+    std::vector<Bytes> receive_responses() override { return gather(local->up[me].pop()); }
+    Bytes receive_response(int party) override {
+        Bytes mine;
+        if (party == me) mine = local->up[me].pop();
+        return gather(mine)[party];
+    }
+    void broadcast_request(const Bytes& b) override { local->down[me].push(b); }
+    void send_request(int party, const Bytes& b) override {
+        if (party == me) local->down[me].push(b);
+    }
+};
+}  // namespace
+
+int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, const cozk_ring_net* ring, int verify,
+                                   cozk_harness_result* res) {
+    if (!h || !hub || !ring || !res || h->local_party < 0 || hub->n_participants != 3 || hub->my_index != h->local_party)
+        return COZK_ERR_INVALID_ARG;
+    memset(res, 0, sizeof *res);
+    res->verified = -1;
+    int me = h->local_party;
+    InProcStar star(3);
+    InProcStarWorker sw(&star, me);
+    CallbackRingNet rn(*ring);
+    PartyState& ps = h->parties[me];
+    ps.error.clear();
+    double t0 = now_ms();
+    std::thread worker([&] {
+        try {
+            worker_main(h, ps, &sw, &rn);
+        } catch (const std::exception& e) {
+            ps.error = e.what();
+            star.abort.flag.store(true);
+        }
+    });
+    ProofBundle proof;
+    std::string why;
+    int verified = -1;
+    int rc = COZK_OK;
+    try {
+        HubStarCoordinator coord(&star, *hub, me);
+        verified = coordinator_main(h, coord, proof, verify != 0, why);
+    } catch (const std::exception& e) {
+        h->error = std::string("coordinator: ") + e.what();
+        star.abort.flag.store(true);
+        rc = COZK_ERR_INTERNAL;
+    }
+    worker.join();
+    double t1 = now_ms();
+    if (!ps.error.empty()) {
+        h->error = "party " + std::to_string(me) + ": " + ps.error;
+        rc = COZK_ERR_INTERNAL;
+    }
+    if (rc != COZK_OK) return rc;
+    if (verified == 0) h->error = "verification failed: " + why;
+    res->verified = verified;
+    res->wall_ms = t1 - t0;
+    res->t_commit_ms = ps.t_commit;
+    res->t_gp_construct_ms = ps.t_construct;
+    res->t_gp_prove_ms = ps.t_gp;
+    res->t_eval_ms = ps.t_eval;
+    res->t_open_ms = ps.t_open;
+    res->t_worker_ms = ps.t_total;
+    res->bytes_star_up = ps.star_up;
+    res->bytes_star_down = ps.star_down;
+    res->bytes_ring = ps.ring_bytes;
+    res->star_messages = ps.star_msgs;
+    h->last_proof = proof.serialize();
+    res->proof_len = h->last_proof.size();
+    Sha256 s;
+    s.update(h->last_proof.data(), h->last_proof.size());
+    s.final(res->proof_digest);
+    return COZK_OK;
+}
+
+// raw copy between any two pointers (device or host) on the context's stream, synchronous: lets a host
+// transport stage ring payloads in its own buffers (torch tensors) without knowing the engine's types
+int cozk_copy(cozk_ctx* ctx, void* dst, const void* src, size_t nbytes) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && (nbytes == 0 || (dst && src)), "cozk_copy: bad argument");
+        if (nbytes) {
+            HIP_TRY(hipMemcpyAsync(dst, src, nbytes, hipMemcpyDefault, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    });
 }
 
 // serialized proof of the last prove (cozk_harness_result.proof_len bytes)

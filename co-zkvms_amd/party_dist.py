@@ -1,0 +1,155 @@
+"""One Rep3 party per process / GPU (BASELINE config 3): torch.distributed transports for the engine's
+network seam.
+  * TorchHub  -> cozk_hub_net.all_gather: variable-length byte all-gather over a gloo (CPU) group -- star
+                 messages are a few hundred bytes, latency-bound; the replicated coordinator inside libcozk
+                 turns the gathered messages into the next challenge on every rank.
+  * TorchRing -> cozk_ring_net.reshare: send to the next party / receive from the previous one.  With the
+                 nccl backend (= RCCL) the payload stays on the GPUs (xGMI); with gloo it is staged through
+                 host memory (rehearsal with several ranks on one GPU).
+No field arithmetic here: this is plumbing, covered by gloo tests on CPU."""
+import ctypes
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .harness import HarnessConfig, HarnessResult, _decl
+
+_AG = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t,
+                       ctypes.POINTER(ctypes.c_size_t))
+_RS = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t)
+
+
+class HubNet(ctypes.Structure):
+    _fields_ = [("user", ctypes.c_void_p), ("n_participants", ctypes.c_int), ("my_index", ctypes.c_int), ("all_gather", _AG)]
+
+
+class RingNetC(ctypes.Structure):
+    _fields_ = [("user", ctypes.c_void_p), ("reshare", _RS)]
+
+
+PARTY_SYMBOLS = ["cozk_harness_create_party", "cozk_harness_prove_distributed", "cozk_copy"]
+
+
+def all_gather_bytes(group, world, payload):
+    """variable-length all-gather of byte strings over `group` (CPU tensors)"""
+    n = torch.tensor([len(payload)], dtype=torch.int64)
+    lens = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(lens, n, group=group)
+    lens = [int(x.item()) for x in lens]
+    m = max(lens + [1])
+    buf = torch.zeros(m, dtype=torch.uint8)
+    if payload:
+        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
+    outs = [torch.zeros(m, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(outs, buf, group=group)
+    return [bytes(o[:l].tolist()) for o, l in zip(outs, lens)]
+
+
+class TorchHub:
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+        self.error = None
+
+        def _ag(_u, send, n, recv, cap, lens):
+            try:
+                mine = ctypes.string_at(send, n) if n else b""
+                parts = all_gather_bytes(self.group, self.world, mine)
+                for i, p in enumerate(parts):
+                    if len(p) > cap:
+                        return 2
+                    ctypes.memmove(recv + i * cap, p, len(p))
+                    lens[i] = len(p)
+                return 0
+            except Exception as e:  # never unwind into C
+                self.error = e
+                return 1
+
+        self._cb = _AG(_ag)
+        self.net = HubNet(None, world, rank, self._cb)
+
+
+class TorchRing:
+    """reshare over torch.distributed P2P.  device=None: host staging (gloo); else CUDA staging tensors (nccl/RCCL)"""
+
+    def __init__(self, ctx_handle, rank, world, group=None, device=None):
+        self.ctx, self.rank, self.world, self.group, self.device = ctx_handle, rank, world, group, device
+        self.error = None
+        self._l = L.lib()
+        self._l.cozk_copy.restype = ctypes.c_int
+        self._l.cozk_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+
+        def _rs(_u, dev_send, dev_recv, nbytes):
+            try:
+                if self.device is not None:
+                    torch.cuda.set_device(self.device)  # callbacks run on the engine's worker thread
+                dev = torch.device("cuda", self.device) if self.device is not None else torch.device("cpu")
+                sbuf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                rbuf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                if self._l.cozk_copy(self.ctx, sbuf.data_ptr(), dev_send, nbytes) != 0:
+                    return 3
+                nxt, prv = (self.rank + 1) % self.world, (self.rank + self.world - 1) % self.world
+                ops = [dist.P2POp(dist.isend, sbuf, nxt, group=self.group), dist.P2POp(dist.irecv, rbuf, prv, group=self.group)]
+                for req in dist.batch_isend_irecv(ops):
+                    req.wait()
+                if self.device is not None:
+                    torch.cuda.synchronize(self.device)
+                if self._l.cozk_copy(self.ctx, dev_recv, rbuf.data_ptr(), nbytes) != 0:
+                    return 3
+                return 0
+            except Exception as e:
+                self.error = e
+                return 1
+
+        self._cb = _RS(_rs)
+        self.net = RingNetC(None, self._cb)
+
+
+class DistributedParty:
+    """this process's party of a 3-party Rep3 proof (`cozk_harness_create_party` / `prove_distributed`)"""
+
+    def __init__(self, party, device=0, **cfgkw):
+        self._l = _decl()
+        self._l.cozk_harness_create_party.restype = ctypes.c_int
+        self._l.cozk_harness_create_party.argtypes = [ctypes.POINTER(HarnessConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self._l.cozk_harness_prove_distributed.restype = ctypes.c_int
+        self._l.cozk_harness_prove_distributed.argtypes = [ctypes.c_void_p, ctypes.POINTER(HubNet), ctypes.POINTER(RingNetC), ctypes.c_int,
+                                                           ctypes.POINTER(HarnessResult)]
+        cfg = HarnessConfig()
+        cfg.mode = L.MODE_REP3
+        cfg.log_n = cfgkw.get("log_n", 10)
+        cfg.n_fr, cfg.n_u16, cfg.n_u32 = cfgkw.get("n_fr", 4), cfgkw.get("n_u16", 1), cfgkw.get("n_u32", 1)
+        cfg.n_flags, cfg.n_small = cfgkw.get("n_flags", 1), cfgkw.get("n_small", 0)
+        cfg.gp_batch = cfgkw.get("gp_batch", 2)
+        cfg.gp_log_leaves = cfgkw.get("gp_log_leaves", cfg.log_n + 1)
+        cfg.precompute = 1 if cfgkw.get("precompute", True) else 0
+        cfg.devices = (ctypes.c_int * 3)(device, device, device)
+        cfg.seed = cfgkw.get("seed", 1)
+        self.party = party
+        h = ctypes.c_void_p()
+        rc = self._l.cozk_harness_create_party(ctypes.byref(cfg), party, ctypes.byref(h))
+        self.h = h
+        if rc != L.OK:
+            msg = self._l.cozk_harness_error(h) if h else b"?"
+            raise L.CozkError(rc, (msg or b"?").decode())
+
+    def ctx_handle(self):
+        return self._l.cozk_harness_ctx(self.h, self.party)
+
+    def prove(self, hub, ring, verify=True):
+        res = HarnessResult()
+        rc = self._l.cozk_harness_prove_distributed(self.h, ctypes.byref(hub.net), ctypes.byref(ring.net), 1 if verify else 0, ctypes.byref(res))
+        if rc != L.OK:
+            for t in (hub, ring):
+                if t.error is not None:
+                    raise t.error
+            raise L.CozkError(rc, (self._l.cozk_harness_error(self.h) or b"?").decode())
+        return res
+
+    def last_error(self):
+        return (self._l.cozk_harness_error(self.h) or b"").decode()
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.cozk_harness_destroy(self.h)
+            self.h = None

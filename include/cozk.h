@@ -312,6 +312,24 @@ const char* cozk_harness_error(const cozk_harness* h);
 int cozk_harness_destroy(cozk_harness* h);
 int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res);
 int cozk_harness_proof_bytes(const cozk_harness* h, uint8_t* out, size_t cap);
+
+/* Distributed form (BASELINE config 3, "one MI355X per party"): one party per process / GPU.  Every process
+ * runs its own copy of the deterministic coordinator; a star gather becomes an all-gather of the parties'
+ * messages through the host transport (torch.distributed / RCCL), the ring reshare goes through
+ * cozk_ring_net on device pointers.  all_gather: participant i contributes `len` bytes; recv holds
+ * n_participants slots of `cap` bytes, lens[i] the received lengths.  Returns 0 on success. */
+typedef struct cozk_hub_net {
+    void* user;
+    int n_participants;
+    int my_index;
+    int (*all_gather)(void* user, const void* send, size_t len, void* recv, size_t cap, size_t* lens);
+} cozk_hub_net;
+int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, cozk_harness** out);
+int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, const cozk_ring_net* ring,
+                                   int verify, cozk_harness_result* res);
+/* synchronous raw copy between any two pointers (device or host) on the context's stream: lets a host
+ * transport stage ring payloads in buffers of its own (e.g. torch tensors) */
+int cozk_copy(cozk_ctx* ctx, void* dst, const void* src, size_t nbytes);
 cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party);
 
 /* ---------------------------------------------------------------- profiling ---------------- */
