@@ -62,6 +62,8 @@ SIGNATURES = {
     "cozk_vec_len": (_sz, [_vp]),
     "cozk_vec_device_ptr": (_vp, [_vp]),
     "cozk_vec_fill_random": (_i, [_vp, _vp, _u64, _i]),
+    "cozk_vec_scale": (_i, [_vp, _vp, _vp]),
+    "cozk_layer_compute_cubic_evals": (_i, [_vp, _vp, _vp, _vp]),
     "cozk_vec_binop": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "cozk_bases_upload": (_i, [_vp, _vp, _vp, _sz, _i, _pp]),
     "cozk_bases_from_scalars": (_i, [_vp, _vp, _vp, _i, _pp]),

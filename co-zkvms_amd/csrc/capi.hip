@@ -61,6 +61,11 @@ __global__ void __launch_bounds__(256) k_fe_binop(const fe* __restrict__ a, cons
     fe_store(out + i, r);
 }
 
+__global__ void __launch_bounds__(256) k_fe_scale(fe* __restrict__ v, size_t n, fe s) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(v + i, Fr::mul(fe_load(v + i), s));
+}
+
 template <class F>
 static void launch_binop(cozk_ctx* ctx, int op, const fe* a, const fe* b, fe* out, size_t n) {
     unsigned grid = (unsigned)((n + 255) / 256);
@@ -217,6 +222,20 @@ int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits
                 k_fill_random_small<uint64_t><<<grid, 256, 0, ctx->stream>>>((uint64_t*)v->d, v->n, seed, max_bits);
                 break;
         }
+        HIP_TRY(hipGetLastError());
+    });
+}
+
+int cozk_vec_scale(cozk_ctx* ctx, cozk_vec* v, const uint64_t s[4]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && v && s && v->kind == COZK_SCALAR_FR, "vec_scale: bad argument");
+        if (v->n == 0) return;
+        fe sc;
+        for (int i = 0; i < 4; i++) {
+            sc.l[2 * i] = (uint32_t)s[i];
+            sc.l[2 * i + 1] = (uint32_t)(s[i] >> 32);
+        }
+        k_fe_scale<<<(unsigned)((v->n + 255) / 256), 256, 0, ctx->stream>>>((fe*)v->d, v->n, sc);
         HIP_TRY(hipGetLastError());
     });
 }

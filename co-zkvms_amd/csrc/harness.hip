@@ -556,6 +556,8 @@ static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundl
     return 1;
 }
 
+#include "host/split_harness.hpp"
+
 // --------------------------------------------------------------------------- C ABI
 extern "C" {
 
@@ -574,16 +576,22 @@ int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out) {
         COZK_REQUIRE(cfg->n_fr + cfg->n_u16 + cfg->n_u32 + cfg->n_flags >= 1, "harness: no polynomials");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->N = (size_t)1 << cfg->log_n;
-        h->parties.resize(h->nparties);
-        for (int p = 0; p < h->nparties; p++) {
-            PartyState& ps = h->parties[p];
-            ps.party = p;
-            int rc = cozk_ctx_create(cfg->devices[p], &ps.ctx);
-            if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
-            ps.own_ctx = true;
-            HIP_TRY(hipSetDevice(ps.ctx->device));
-            setup_party(h, ps);
-        }
+        COZK_REQUIRE(cfg->log_workers >= 0 && cfg->log_workers <= 3, "harness: log_workers must be 0..3");
+        int W = 1 << cfg->log_workers;
+        if (W > 1) COZK_REQUIRE((cfg->gp_batch & (cfg->gp_batch - 1)) == 0, "split: gp_batch must be a power of two");
+        h->parties.resize((size_t)h->nparties * W);
+        for (int w = 0; w < W; w++)
+            for (int p = 0; p < h->nparties; p++) {
+                PartyState& ps = h->parties[(size_t)w * h->nparties + p];
+                ps.party = p;
+                int dev = cfg->mode == COZK_MODE_REP3 ? cfg->devices[p] : (W > 1 ? cfg->worker_devices[w] : cfg->devices[0]);
+                int rc = cozk_ctx_create(dev, &ps.ctx);
+                if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
+                ps.own_ctx = true;
+                HIP_TRY(hipSetDevice(ps.ctx->device));
+                if (W > 1) setup_participant_split(h, ps, w);
+                else setup_party(h, ps);
+            }
     } catch (const CozkError& e) {
         h->error = e.what();
         *out = h;  // caller reads the error, then destroys
@@ -620,14 +628,18 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
     if (!h || !res) return COZK_ERR_INVALID_ARG;
     memset(res, 0, sizeof *res);
     res->verified = -1;
-    int np = h->nparties;
+    if (h->local_party >= 0) return COZK_ERR_INVALID_ARG;  // distributed harness: use cozk_harness_prove_distributed
+    const int W = 1 << h->cfg.log_workers;
+    const int nparty = h->nparties;
+    int np = nparty * W;  // participants: id = worker * nparty + party
     InProcStar star(np);
-    InProcRing ring(&star.abort);
+    std::vector<std::unique_ptr<InProcRing>> rings;  // one ring per worker index (its three parties)
+    for (int w = 0; w < W; w++) rings.emplace_back(new InProcRing(&star.abort));
     std::vector<std::unique_ptr<InProcStarWorker>> sw;
     std::vector<std::unique_ptr<InProcRingNet>> rn;
     for (int p = 0; p < np; p++) {
         sw.emplace_back(new InProcStarWorker(&star, p));
-        rn.emplace_back(np == 3 ? new InProcRingNet(&ring, p) : nullptr);
+        rn.emplace_back(nparty == 3 ? new InProcRingNet(rings[p / nparty].get(), p % nparty) : nullptr);
         h->parties[p].error.clear();
     }
     std::vector<std::thread> threads;
@@ -635,7 +647,8 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
     for (int p = 0; p < np; p++) {
         threads.emplace_back([&, p] {
             try {
-                worker_main(h, h->parties[p], sw[p].get(), rn[p].get());
+                if (W > 1) worker_main_split(h, h->parties[p], p / nparty, sw[p].get(), rn[p].get());
+                else worker_main(h, h->parties[p], sw[p].get(), rn[p].get());
             } catch (const std::exception& e) {
                 h->parties[p].error = e.what();
                 star.abort.flag.store(true);
@@ -648,7 +661,7 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
     int rc = COZK_OK;
     try {
         InProcStarCoordinator coord(&star);
-        verified = coordinator_main(h, coord, proof, verify != 0, why);
+        verified = W > 1 ? coordinator_main_split(h, coord, proof, verify != 0, why) : coordinator_main(h, coord, proof, verify != 0, why);
     } catch (const std::exception& e) {
         h->error = std::string("coordinator: ") + e.what();
         star.abort.flag.store(true);
@@ -658,7 +671,7 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
     double t1 = now_ms();
     for (int p = 0; p < np; p++) {
         if (!h->parties[p].error.empty()) {
-            h->error = "party " + std::to_string(p) + ": " + h->parties[p].error;
+            h->error = "participant " + std::to_string(p) + ": " + h->parties[p].error;
             rc = COZK_ERR_INTERNAL;
         }
     }
@@ -843,7 +856,7 @@ int cozk_harness_proof_bytes(const cozk_harness* h, uint8_t* out, size_t cap) {
 
 // context of party p (profiling hooks: cozk_prof_enable / cozk_prof_read)
 cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party) {
-    if (!h || party < 0 || party >= h->nparties) return nullptr;
+    if (!h || party < 0 || party >= (int)h->parties.size()) return nullptr;
     return h->parties[party].ctx;
 }
 

@@ -433,7 +433,7 @@ static inline g1_affine abi_to_g1(const uint64_t* xy, int inf) {
 struct PST13 {
     // MultilinearPC::setup(nv, rng) with the trapdoor t supplied (PST13::setup, pst13.rs:49-62).
     // powers_of_g[i][b] = g^{eq_le(t[i..], b)}: index bit j of b pairs with t[i + j].
-    static std::unique_ptr<PST13Setup> setup(cozk_ctx* ctx, const std::vector<fe>& t, int precompute = 1) {
+    static std::unique_ptr<PST13Setup> setup(cozk_ctx* ctx, const std::vector<fe>& t, int precompute = 1, const g1_affine* generator = nullptr) {
         std::unique_ptr<PST13Setup> s(new PST13Setup());
         int nv = (int)t.size();
         COZK_REQUIRE(nv >= 1 && nv <= 26, "PST13::setup: nv out of range");
@@ -441,6 +441,9 @@ struct PST13 {
         s->trapdoor = t;
         s->g.x = Fq::one();
         s->g.y = Fq::from_u64(2);
+        // a worker sub-net's slice of a larger SRS is the local table over its low variables with the
+        // generator pre-multiplied by eq(t_high, worker index)
+        if (generator) s->g = *generator;
         size_t total = ((size_t)1 << (nv + 1)) - 2;
         cozk_vec* sc = nullptr;
         rc_check(cozk_vec_alloc(ctx, total, COZK_SCALAR_FR, &sc), ctx, "vec_alloc");
@@ -485,7 +488,8 @@ struct PST13 {
 
     // `open` (pst13.rs:428-474) on the share-a evaluations; point already reversed by the caller.
     // All nv MSMs go out as one launch set over `halves`.
-    static std::vector<g1_affine> open(cozk_ctx* ctx, const PST13Setup& s, const cozk_vec* evals, const std::vector<fe>& point) {
+    static std::vector<g1_affine> open(cozk_ctx* ctx, const PST13Setup& s, const cozk_vec* evals, const std::vector<fe>& point,
+                                       fe* final_value = nullptr) {
         int nv = s.nv;
         COZK_REQUIRE(cozk_vec_len(evals) == ((size_t)1 << nv), "PST13::open: invalid size of polynomial");
         COZK_REQUIRE((int)point.size() == nv, "PST13::open: point length");
@@ -505,6 +509,11 @@ struct PST13 {
             view.n = 2 * half;
             rc_check(cozk_pst_fold(ctx, &view, p, q[i].h, r[i].h), ctx, "pst_fold");
             cur = r[i].h;
+        }
+        if (final_value) {  // the fully folded value r[0][0] (worker sub-nets hand it on for the last k folds)
+            uint64_t v[4];
+            rc_check(cozk_vec_download(ctx, nv > 0 ? r[nv - 1].h : evals, v), ctx, "vec_download");
+            *final_value = fe_from_u64x4(v);
         }
         std::vector<const cozk_vec*> qs(nv);
         std::vector<size_t> offs(nv);

@@ -1168,36 +1168,52 @@ int cozk_spliteq_bind(cozk_ctx* ctx, cozk_spliteq* e, const uint64_t r[4]) {
 
 // Rep3BatchedCubicSumcheckWorker::compute_cubic (dense_interleaved_poly.rs:210-365): returns the 4
 // additive coefficient shares of the round polynomial through evals [g0, claim - g0, g2, g3]
+static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq, fe s[3]) {
+    size_t nch = (l->len + 3) / 4;
+    unsigned gx = grid_capped(nch);
+    if (gx > 1024) gx = 1024;
+    ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
+    fe* partial = ctx->scratch.as<fe>();
+    fe* res = result_slot(ctx, 3);
+    const fe* a = l->buf[l->cur][0];
+    const fe* b = l->buf[l->cur][1];
+    const fe* E1 = eq->E1[eq->c1];
+    const fe* E2 = eq->E2[eq->c2];
+    bool nested = eq->E1_len != 1;
+    if (l->mode == COZK_MODE_REP3) {
+        if (nested) k_layer_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+        else k_layer_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+    } else {
+        if (nested) k_layer_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+        else k_layer_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+    }
+    k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+    HIP_TRY(hipGetLastError());
+    fetch_fe(ctx, res, 3, s);
+}
+
 int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq, const uint64_t prev_claim[4],
                              uint64_t out_coeffs[16]) {
     return cozk_guard(ctx, [&] {
         COZK_REQUIRE(ctx && l && eq && prev_claim && out_coeffs, "compute_cubic: bad argument");
-        size_t nch = (l->len + 3) / 4;
-        unsigned gx = grid_capped(nch);
-        if (gx > 1024) gx = 1024;
-        ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
-        fe* partial = ctx->scratch.as<fe>();
-        fe* res = result_slot(ctx, 3);
-        const fe* a = l->buf[l->cur][0];
-        const fe* b = l->buf[l->cur][1];
-        const fe* E1 = eq->E1[eq->c1];
-        const fe* E2 = eq->E2[eq->c2];
-        bool nested = eq->E1_len != 1;
-        if (l->mode == COZK_MODE_REP3) {
-            if (nested) k_layer_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
-            else k_layer_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
-        } else {
-            if (nested) k_layer_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
-            else k_layer_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
-        }
-        k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
-        HIP_TRY(hipGetLastError());
         fe s[3];
-        fetch_fe(ctx, res, 3, s);
+        layer_cubic_sums(ctx, l, eq, s);
         fe ev[4] = {s[0], Fr::sub(fe_from_u64x4(prev_claim), s[0]), s[1], s[2]};
         fe cf[4];
         unipoly_from_evals(ev, 4, cf);
         for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], out_coeffs + 4 * i);
+    });
+}
+
+// the raw additive sums g(0), g(2), g(3) of compute_cubic, for a worker sub-net that cannot derive g(1) from
+// the (global) previous claim: the coordinator inserts claim - g(0), as the reference does for the primary
+// sumcheck (jolt/vm/instruction_lookups/worker.rs:593-597, coordinator.rs:131-132)
+int cozk_layer_compute_cubic_evals(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq, uint64_t out_evals[12]) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && l && eq && out_evals, "compute_cubic_evals: bad argument");
+        fe s[3];
+        layer_cubic_sums(ctx, l, eq, s);
+        for (int i = 0; i < 3; i++) fe_to_u64x4(s[i], out_evals + 4 * i);
     });
 }
 

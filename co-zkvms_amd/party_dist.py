@@ -125,6 +125,8 @@ class DistributedParty:
         cfg.precompute = 1 if cfgkw.get("precompute", True) else 0
         cfg.devices = (ctypes.c_int * 3)(device, device, device)
         cfg.seed = cfgkw.get("seed", 1)
+        cfg.log_workers = 0
+        cfg.worker_devices = (ctypes.c_int * 8)(*([device] * 8))
         self.party = party
         h = ctypes.c_void_p()
         rc = self._l.cozk_harness_create_party(ctypes.byref(cfg), party, ctypes.byref(h))

@@ -86,6 +86,8 @@ int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits
 #define COZK_OP_MUL 2
 int cozk_vec_binop(cozk_ctx* ctx, int op, int base_field, const cozk_vec* a, const cozk_vec* b,
                    cozk_vec* out);
+/* v[i] *= s (Fr) in place */
+int cozk_vec_scale(cozk_ctx* ctx, cozk_vec* v, const uint64_t s[4]);
 
 /* ---------------------------------------------------------------- MSM seam ---------------- */
 /* Upload SRS points (`ck.powers_of_g[i]`, co-jolt/src/poly/commitment/pst13.rs:286-287,461-462) once;
@@ -211,6 +213,10 @@ int cozk_layer_bind(cozk_ctx* ctx, cozk_layer* l, const uint64_t r[4]);
  * coefficient shares (low -> high) of the round polynomial */
 int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,
                              const uint64_t prev_claim[4], uint64_t out_coeffs[16]);
+/* raw sums g(0), g(2), g(3) of compute_cubic (12 u64) for worker sub-nets: the coordinator inserts
+ * claim - g(0) itself, as for the reference's primary sumcheck (instruction_lookups/worker.rs:593-597) */
+int cozk_layer_compute_cubic_evals(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,
+                                   uint64_t out_evals[12]);
 /* final_claims (dense_interleaved_poly.rs:367-372): out = L.a, L.b, R.a, R.b (b = 0 for PLAIN) */
 int cozk_layer_final_claims(cozk_ctx* ctx, const cozk_layer* l, uint64_t out[16]);
 /* local half of layer_output -> mul_vec (dense_interleaved_poly.rs:122-141; local product
@@ -297,6 +303,10 @@ typedef struct cozk_harness_config {
     int precompute;    /* build the 16-window SRS table */
     int devices[3];    /* HIP device per party */
     uint64_t seed;
+    int log_workers;   /* worker sub-nets per party: 2^log_workers workers, each holding one high-variable chunk
+                          of every polynomial and gp_batch / 2^log_workers circuits (reference: split_poly,
+                          dense_mlpoly.rs:275-301; co-jolt/README.md:44).  0 = the single-worker path. */
+    int worker_devices[8]; /* HIP device per worker index (in-process form) */
 } cozk_harness_config;
 typedef struct cozk_harness_result {
     int verified; /* 1 accepted, 0 rejected, -1 verifier not run */
