@@ -7,8 +7,13 @@ plain prover on one MI355X, "kernels only": 128 committed polynomials (64 unifor
 one dense grand product of 8 circuits x 2^21 leaves (construct + GKR prove), batch_evaluate + RLC of
 all 128 polynomials at two points, the opening-reduction sumcheck and the PST13 opening (20 MSMs).
 A "step" = one full pass over that trace with the witness and SRS already resident in HBM.
-N > 1: one process per GPU, each rank proves its own 2^20-cycle trace segment (independent segments,
-no data-path collective; weak scaling); ranks only meet at the barriers and the digest gather.
+N > 1 (one process per GPU), `--shard worker` (default): ONE proof of a 2^20 * N-cycle trace sharded over the
+N GPUs as worker sub-nets -- every polynomial chunked over its high variables (the reference's split_poly,
+co-jolt/src/poly/dense_mlpoly.rs:275-301), the 8 grand-product circuits divided among the workers, the last
+log2(N) sumcheck rounds / PST folds finished on the gathered finals; each GPU keeps 2^20 cycles of work (weak
+scaling).  The only exchange step is the per-round star gather (a few hundred bytes per rank), carried as an
+all-gather over torch.distributed with a replicated coordinator on every rank; there is no bulk collective.
+`--shard segment`: N independent 2^20-cycle segments instead (no exchange at all).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (MSM bucket accumulation,
 k_msm_accum0), timed live with HIP events on the stream it is launched on; `cpu_baseline` is the
@@ -35,6 +40,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the padded trace length (cycles)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16, help="trace length of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--shard", choices=["worker", "segment"], default="worker",
+                    help="N>1: one proof sharded as worker sub-nets (default) or N independent trace segments")
     args = ap.parse_args()
 
     import torch
@@ -52,9 +59,35 @@ def main():
     grp = dist.Group(device=dev)
 
     log_n = args.log_n
-    workload = dict(n_fr=64, n_u16=32, n_u32=16, n_flags=16, n_small=0, gp_batch=8, gp_log_leaves=log_n + 1)
+    split = world > 1 and args.shard == "worker"
+    if split and (world & (world - 1) or world > 8):
+        raise SystemExit("--shard worker needs a power-of-two number of GPUs <= 8")
+    logw = world.bit_length() - 1 if split else 0
+    total_log_n = log_n + logw  # one proof over the whole 2^(log_n + log2 N)-cycle trace
+    workload = dict(n_fr=64, n_u16=32, n_u32=16, n_flags=16, n_small=0, gp_batch=8, gp_log_leaves=total_log_n + 1)
     t_setup = time.time()
-    h = pkg.Harness(mode="plain", log_n=log_n, seed=dist.shard_seed(2026, rank), devices=(dev, dev, dev), **workload)
+    if split:
+        import torch.distributed as tdist
+        pd = importlib.import_module("co-zkvms_amd.party_dist")
+        hub_group = tdist.new_group(backend="gloo")  # star messages: a few hundred bytes, CPU tensors
+        party = pd.DistributedParty(0, device=dev, worker=rank, mode="plain", log_workers=logw, log_n=total_log_n, seed=2026, **workload)
+        hub = pd.TorchHub(rank, world, hub_group)
+
+        class _H:  # same surface as Harness for the timed loop below
+            def prove(self, verify=True):
+                return party.prove(hub, None, verify=verify)
+
+            def last_error(self):
+                return party.last_error()
+
+            def party_ctx_handle(self, _p=0):
+                return party.ctx_handle()
+
+            def close(self):
+                party.close()
+        h = _H()
+    else:
+        h = pkg.Harness(mode="plain", log_n=log_n, seed=dist.shard_seed(2026, rank), devices=(dev, dev, dev), **workload)
     t_setup = time.time() - t_setup
 
     # correctness gate (untimed): the assembled proof verifies (GKR, leaf evaluation, reduction sumcheck,
@@ -129,7 +162,10 @@ def main():
            "config": {"workload": "configs[1] restated (SURVEY 8d): 2^%d-cycle trace per GPU, plain prover, 128 polys "
                                   "(64 Fr + 32 u16 + 16 u32 + 16 flags) PST13 batch commit, dense grand product 8 x 2^%d leaves, "
                                   "batch evaluate + opening reduction + PST13 open" % (log_n, log_n + 1),
-                      "log_n": log_n, "polys": 128, "gp_batch": 8, "parallelism": "independent trace segment per GPU" if world > 1 else "single GPU"},
+                      "log_n": log_n, "polys": 128, "gp_batch": 8,
+                      "parallelism": ("single GPU" if world == 1 else
+                                      ("one proof of a 2^%d-cycle trace sharded over %d worker sub-nets (high-variable chunks), star all-gather per round" % (total_log_n, world)
+                                       if split else "independent trace segment per GPU"))},
            "phases_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()},
            "setup_s": round(t_setup, 2), "proof_bytes": int(res.proof_len), "proof_sha256": [d.hex()[:16] for d in digests],
            "roofline": roofline}

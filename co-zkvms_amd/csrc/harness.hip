@@ -112,7 +112,8 @@ double now_ms() {
 
 struct cozk_harness {
     cozk_harness_config cfg;
-    int local_party = -1;  // >= 0: distributed form, only this party lives in this process
+    int local_party = -1;  // >= 0: distributed form, only this (party, worker) participant lives in this process
+    int local_worker = 0;
     int nparties = 1;
     size_t N = 0;
     std::vector<PartyState> parties;
@@ -544,7 +545,7 @@ static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundl
         joint_claim = Fr::add(joint_claim, Fr::mul(gp_pw[i], Fr::mul(sc, proof.reduced.sumcheck_claims[i])));
     }
     std::vector<fe> rev(rs.rbegin(), rs.rend());
-    const PST13Setup& vsetup = *h->parties[h->local_party >= 0 ? h->local_party : 0].setup;  // same SRS everywhere
+    const PST13Setup& vsetup = *h->parties[h->local_party >= 0 ? h->local_worker * h->nparties + h->local_party : 0].setup;  // same SRS everywhere
     if (!PST13::check_with_trapdoor(vsetup, joint_c, rev, joint_claim, proof.reduced.joint_opening_proof)) {
         why = "PST13 opening check failed";
         return 0;
@@ -705,28 +706,37 @@ int cozk_harness_prove(cozk_harness* h, int verify, cozk_harness_result* res) {
 // the parties' messages through the host's transport (`cozk_hub_net`, e.g. torch.distributed / RCCL), after
 // which each copy derives the same challenge -- no coordinator process, no extra hop.  The ring reshare goes
 // through `cozk_ring_net` on device pointers (an RCCL send/recv pair over xGMI).
-int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, cozk_harness** out) {
+int cozk_harness_create_participant(const cozk_harness_config* cfg, int local_party, int local_worker, cozk_harness** out) {
     if (!cfg || !out) return COZK_ERR_INVALID_ARG;
     *out = nullptr;
     cozk_harness* h = new cozk_harness();
     h->cfg = *cfg;
     try {
-        COZK_REQUIRE(cfg->mode == COZK_MODE_REP3 && local_party >= 0 && local_party < 3, "harness_create_party: REP3 with party 0..2");
+        COZK_REQUIRE(cfg->mode == COZK_MODE_PLAIN || cfg->mode == COZK_MODE_REP3, "harness: bad mode");
+        int np = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
+        COZK_REQUIRE(cfg->log_workers >= 0 && cfg->log_workers <= 3, "harness: log_workers must be 0..3");
+        int W = 1 << cfg->log_workers;
+        COZK_REQUIRE(local_party >= 0 && local_party < np && local_worker >= 0 && local_worker < W, "harness_create_participant: bad (party, worker)");
         COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24 && cfg->gp_batch >= 1 && cfg->gp_log_leaves >= 1, "harness: bad shape");
         int gbits = 0;
         while ((1 << gbits) < cfg->gp_batch) gbits++;
         COZK_REQUIRE(gbits + cfg->gp_log_leaves >= cfg->log_n, "harness: grand-product point shorter than the opening point");
-        h->nparties = 3;
+        if (W > 1) COZK_REQUIRE((cfg->gp_batch & (cfg->gp_batch - 1)) == 0, "split: gp_batch must be a power of two");
+        h->nparties = np;
         h->local_party = local_party;
+        h->local_worker = local_worker;
         h->N = (size_t)1 << cfg->log_n;
-        h->parties.resize(3);
-        for (int p = 0; p < 3; p++) h->parties[p].party = p;
-        PartyState& ps = h->parties[local_party];
-        int rc = cozk_ctx_create(cfg->devices[local_party], &ps.ctx);
+        h->parties.resize((size_t)np * W);
+        for (int w = 0; w < W; w++)
+            for (int p = 0; p < np; p++) h->parties[(size_t)w * np + p].party = p;
+        PartyState& ps = h->parties[(size_t)local_worker * np + local_party];
+        int dev = cfg->mode == COZK_MODE_REP3 ? cfg->devices[local_party] : (W > 1 ? cfg->worker_devices[local_worker] : cfg->devices[0]);
+        int rc = cozk_ctx_create(dev, &ps.ctx);
         if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
         ps.own_ctx = true;
         HIP_TRY(hipSetDevice(ps.ctx->device));
-        setup_party(h, ps);
+        if (W > 1) setup_participant_split(h, ps, local_worker);
+        else setup_party(h, ps);
     } catch (const CozkError& e) {
         h->error = e.what();
         *out = h;
@@ -738,6 +748,10 @@ int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, c
     }
     *out = h;
     return COZK_OK;
+}
+
+int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, cozk_harness** out) {
+    return cozk_harness_create_participant(cfg, local_party, 0, out);
 }
 
 namespace {
@@ -776,20 +790,23 @@ struct HubStarCoordinator : StarNetCoordinator {
 
 int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, const cozk_ring_net* ring, int verify,
                                    cozk_harness_result* res) {
-    if (!h || !hub || !ring || !res || h->local_party < 0 || hub->n_participants != 3 || hub->my_index != h->local_party)
-        return COZK_ERR_INVALID_ARG;
+    if (!h || !hub || !res || h->local_party < 0) return COZK_ERR_INVALID_ARG;
+    const int W = 1 << h->cfg.log_workers;
+    const int nparty = h->nparties;
+    int me = h->local_worker * nparty + h->local_party;
+    if (hub->n_participants != nparty * W || hub->my_index != me || (nparty == 3 && !ring)) return COZK_ERR_INVALID_ARG;
     memset(res, 0, sizeof *res);
     res->verified = -1;
-    int me = h->local_party;
-    InProcStar star(3);
+    InProcStar star(nparty * W);
     InProcStarWorker sw(&star, me);
-    CallbackRingNet rn(*ring);
+    std::unique_ptr<CallbackRingNet> rnp(nparty == 3 ? new CallbackRingNet(*ring) : nullptr);
     PartyState& ps = h->parties[me];
     ps.error.clear();
     double t0 = now_ms();
     std::thread worker([&] {
         try {
-            worker_main(h, ps, &sw, &rn);
+            if (W > 1) worker_main_split(h, ps, h->local_worker, &sw, rnp.get());
+            else worker_main(h, ps, &sw, rnp.get());
         } catch (const std::exception& e) {
             ps.error = e.what();
             star.abort.flag.store(true);
@@ -801,7 +818,7 @@ int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, con
     int rc = COZK_OK;
     try {
         HubStarCoordinator coord(&star, *hub, me);
-        verified = coordinator_main(h, coord, proof, verify != 0, why);
+        verified = W > 1 ? coordinator_main_split(h, coord, proof, verify != 0, why) : coordinator_main(h, coord, proof, verify != 0, why);
     } catch (const std::exception& e) {
         h->error = std::string("coordinator: ") + e.what();
         star.abort.flag.store(true);
@@ -810,7 +827,7 @@ int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, con
     worker.join();
     double t1 = now_ms();
     if (!ps.error.empty()) {
-        h->error = "party " + std::to_string(me) + ": " + ps.error;
+        h->error = "participant " + std::to_string(me) + ": " + ps.error;
         rc = COZK_ERR_INTERNAL;
     }
     if (rc != COZK_OK) return rc;

@@ -28,22 +28,35 @@ class RingNetC(ctypes.Structure):
     _fields_ = [("user", ctypes.c_void_p), ("reshare", _RS)]
 
 
-PARTY_SYMBOLS = ["cozk_harness_create_party", "cozk_harness_prove_distributed", "cozk_copy"]
+PARTY_SYMBOLS = ["cozk_harness_create_party", "cozk_harness_create_participant", "cozk_harness_prove_distributed", "cozk_copy"]
+
+
+_FAST = 2040  # payload bytes that travel with the length header in the single-collective fast path
 
 
 def all_gather_bytes(group, world, payload):
-    """variable-length all-gather of byte strings over `group` (CPU tensors)"""
-    n = torch.tensor([len(payload)], dtype=torch.int64)
-    lens = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
-    dist.all_gather(lens, n, group=group)
-    lens = [int(x.item()) for x in lens]
-    m = max(lens + [1])
-    buf = torch.zeros(m, dtype=torch.uint8)
-    if payload:
-        buf[:len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8)
-    outs = [torch.zeros(m, dtype=torch.uint8) for _ in range(world)]
+    """variable-length all-gather of byte strings over `group` (CPU tensors).  Round messages are a few
+    hundred bytes: they ride one all_gather of fixed 2 KiB slots ([u64 length | payload]); only if some
+    participant's message is longer does a second, max-length all_gather follow (every rank sees all the
+    lengths after the first one, so they agree on it without extra traffic)."""
+    n = len(payload)
+    slot = bytearray(8 + _FAST)
+    slot[:8] = n.to_bytes(8, "little")
+    if n <= _FAST:
+        slot[8:8 + n] = payload
+    buf = torch.frombuffer(slot, dtype=torch.uint8)
+    outs = [torch.empty(8 + _FAST, dtype=torch.uint8) for _ in range(world)]
     dist.all_gather(outs, buf, group=group)
-    return [bytes(o[:l].tolist()) for o, l in zip(outs, lens)]
+    raw = [o.numpy().tobytes() for o in outs]
+    lens = [int.from_bytes(r[:8], "little") for r in raw]
+    if max(lens) <= _FAST:
+        return [r[8:8 + l] for r, l in zip(raw, lens)]
+    m = max(lens)
+    big = bytearray(m)
+    big[:n] = payload
+    outs2 = [torch.empty(m, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(outs2, torch.frombuffer(big, dtype=torch.uint8), group=group)
+    return [o.numpy().tobytes()[:l] for o, l in zip(outs2, lens)]
 
 
 class TorchHub:
@@ -106,17 +119,20 @@ class TorchRing:
 
 
 class DistributedParty:
-    """this process's party of a 3-party Rep3 proof (`cozk_harness_create_party` / `prove_distributed`)"""
+    """this process's participant -- (party, worker) -- of one distributed proof
+    (`cozk_harness_create_participant` / `cozk_harness_prove_distributed`): a party of a 3-party Rep3 run,
+    and/or one worker sub-net (high-variable chunk) of the plain / Rep3 prover"""
 
-    def __init__(self, party, device=0, **cfgkw):
+    def __init__(self, party, device=0, worker=0, mode="rep3", log_workers=0, **cfgkw):
         self._l = _decl()
-        self._l.cozk_harness_create_party.restype = ctypes.c_int
-        self._l.cozk_harness_create_party.argtypes = [ctypes.POINTER(HarnessConfig), ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
+        self._l.cozk_harness_create_participant.restype = ctypes.c_int
+        self._l.cozk_harness_create_participant.argtypes = [ctypes.POINTER(HarnessConfig), ctypes.c_int, ctypes.c_int,
+                                                            ctypes.POINTER(ctypes.c_void_p)]
         self._l.cozk_harness_prove_distributed.restype = ctypes.c_int
         self._l.cozk_harness_prove_distributed.argtypes = [ctypes.c_void_p, ctypes.POINTER(HubNet), ctypes.POINTER(RingNetC), ctypes.c_int,
                                                            ctypes.POINTER(HarnessResult)]
         cfg = HarnessConfig()
-        cfg.mode = L.MODE_REP3
+        cfg.mode = L.MODE_REP3 if mode == "rep3" else L.MODE_PLAIN
         cfg.log_n = cfgkw.get("log_n", 10)
         cfg.n_fr, cfg.n_u16, cfg.n_u32 = cfgkw.get("n_fr", 4), cfgkw.get("n_u16", 1), cfgkw.get("n_u32", 1)
         cfg.n_flags, cfg.n_small = cfgkw.get("n_flags", 1), cfgkw.get("n_small", 0)
@@ -125,25 +141,28 @@ class DistributedParty:
         cfg.precompute = 1 if cfgkw.get("precompute", True) else 0
         cfg.devices = (ctypes.c_int * 3)(device, device, device)
         cfg.seed = cfgkw.get("seed", 1)
-        cfg.log_workers = 0
+        cfg.log_workers = log_workers
         cfg.worker_devices = (ctypes.c_int * 8)(*([device] * 8))
-        self.party = party
+        self.party, self.worker = party, worker
+        self.nparties = 3 if mode == "rep3" else 1
+        self.index = worker * self.nparties + party
         h = ctypes.c_void_p()
-        rc = self._l.cozk_harness_create_party(ctypes.byref(cfg), party, ctypes.byref(h))
+        rc = self._l.cozk_harness_create_participant(ctypes.byref(cfg), party, worker, ctypes.byref(h))
         self.h = h
         if rc != L.OK:
             msg = self._l.cozk_harness_error(h) if h else b"?"
             raise L.CozkError(rc, (msg or b"?").decode())
 
     def ctx_handle(self):
-        return self._l.cozk_harness_ctx(self.h, self.party)
+        return self._l.cozk_harness_ctx(self.h, self.index)
 
     def prove(self, hub, ring, verify=True):
         res = HarnessResult()
-        rc = self._l.cozk_harness_prove_distributed(self.h, ctypes.byref(hub.net), ctypes.byref(ring.net), 1 if verify else 0, ctypes.byref(res))
+        rc = self._l.cozk_harness_prove_distributed(self.h, ctypes.byref(hub.net), ctypes.byref(ring.net) if ring is not None else None,
+                                                    1 if verify else 0, ctypes.byref(res))
         if rc != L.OK:
             for t in (hub, ring):
-                if t.error is not None:
+                if t is not None and t.error is not None:
                     raise t.error
             raise L.CozkError(rc, (self._l.cozk_harness_error(self.h) or b"?").decode())
         return res

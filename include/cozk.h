@@ -335,6 +335,10 @@ typedef struct cozk_hub_net {
     int (*all_gather)(void* user, const void* send, size_t len, void* recv, size_t cap, size_t* lens);
 } cozk_hub_net;
 int cozk_harness_create_party(const cozk_harness_config* cfg, int local_party, cozk_harness** out);
+/* one (party, worker) participant of the worker sub-net form (cfg.log_workers > 0): the hub then has
+ * nparties * 2^log_workers participants, index = worker * nparties + party; ring may be NULL for MODE_PLAIN */
+int cozk_harness_create_participant(const cozk_harness_config* cfg, int local_party, int local_worker,
+                                    cozk_harness** out);
 int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, const cozk_ring_net* ring,
                                    int verify, cozk_harness_result* res);
 /* synchronous raw copy between any two pointers (device or host) on the context's stream: lets a host

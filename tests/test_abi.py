@@ -25,7 +25,7 @@ def test_header_symbols_exported(cozk):
     from importlib import import_module
     hp = import_module("co-zkvms_amd.harness")
     wk = import_module("co-zkvms_amd.workers")
-    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS + wk.WORKER_SYMBOLS + ["cozk_harness_create_party", "cozk_harness_prove_distributed", "cozk_copy"]:
+    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS + wk.WORKER_SYMBOLS + ["cozk_harness_create_party", "cozk_harness_create_participant", "cozk_harness_prove_distributed", "cozk_copy"]:
         assert n in names, n
 
 
