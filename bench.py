@@ -40,6 +40,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the padded trace length (cycles)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16, help="trace length of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--hub", choices=["shm", "gloo"], default="shm", help="transport of the per-round star messages (--shard worker)")
     ap.add_argument("--shard", choices=["worker", "segment"], default="worker",
                     help="N>1: one proof sharded as worker sub-nets (default) or N independent trace segments")
     args = ap.parse_args()
@@ -69,9 +70,11 @@ def main():
     if split:
         import torch.distributed as tdist
         pd = importlib.import_module("co-zkvms_amd.party_dist")
-        hub_group = tdist.new_group(backend="gloo")  # star messages: a few hundred bytes, CPU tensors
+        hub_group = tdist.new_group(backend="gloo")  # CPU group: names the segment / carries the fallback hub
         party = pd.DistributedParty(0, device=dev, worker=rank, mode="plain", log_workers=logw, log_n=total_log_n, seed=2026, **workload)
-        hub = pd.TorchHub(rank, world, hub_group)
+        # star messages are a few hundred bytes per round, ~300 rounds per proof: on one node they go through
+        # libcozk's shared-memory mailboxes (~1 us) rather than a socket collective (~100 us)
+        hub = pd.ShmHub(rank, world, hub_group) if args.hub == "shm" else pd.TorchHub(rank, world, hub_group)
 
         class _H:  # same surface as Harness for the timed loop below
             def prove(self, verify=True):

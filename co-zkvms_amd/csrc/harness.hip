@@ -759,18 +759,21 @@ struct HubStarCoordinator : StarNetCoordinator {
     InProcStar* local;  // only slot `me` is used: the local worker's up/down channels
     cozk_hub_net hub;
     int me;
+    std::unique_ptr<uint8_t[]> recv_buf;  // n x 256 KiB landing slots, allocated once (rounds are ~1 us apart)
+    std::vector<size_t> lens;
     HubStarCoordinator(InProcStar* l, const cozk_hub_net& h, int me_) : local(l), hub(h), me(me_) {}
     std::vector<Bytes> gather(const Bytes& mine) {
         const size_t cap = 1 << 18;
-        std::vector<uint8_t> recv((size_t)hub.n_participants * cap);
-        std::vector<size_t> lens((size_t)hub.n_participants, 0);
+        if (!recv_buf) recv_buf.reset(new uint8_t[(size_t)hub.n_participants * cap]);
+        uint8_t* recv = recv_buf.get();
+        lens.assign((size_t)hub.n_participants, 0);
         if (mine.size() > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: message larger than the 256 KiB slot");
-        if (hub.all_gather(hub.user, mine.data(), mine.size(), recv.data(), cap, lens.data()) != 0)
+        if (hub.all_gather(hub.user, mine.data(), mine.size(), recv, cap, lens.data()) != 0)
             throw CozkError(COZK_ERR_INTERNAL, "hub all_gather callback failed");
         std::vector<Bytes> out;
         for (int p = 0; p < hub.n_participants; p++) {
             if (lens[p] > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: bad length");
-            out.emplace_back(recv.begin() + (size_t)p * cap, recv.begin() + (size_t)p * cap + lens[p]);
+            out.emplace_back(recv + (size_t)p * cap, recv + (size_t)p * cap + lens[p]);
         }
         return out;
     }

@@ -28,7 +28,8 @@ class RingNetC(ctypes.Structure):
     _fields_ = [("user", ctypes.c_void_p), ("reshare", _RS)]
 
 
-PARTY_SYMBOLS = ["cozk_harness_create_party", "cozk_harness_create_participant", "cozk_harness_prove_distributed", "cozk_copy"]
+PARTY_SYMBOLS = ["cozk_shm_hub_open", "cozk_shm_hub_net", "cozk_shm_hub_unlink", "cozk_shm_hub_set_timeout_ms", "cozk_shm_hub_abort", "cozk_shm_hub_close",
+                 "cozk_harness_create_party", "cozk_harness_create_participant", "cozk_harness_prove_distributed", "cozk_copy"]
 
 
 _FAST = 2040  # payload bytes that travel with the length header in the single-collective fast path
@@ -80,6 +81,81 @@ class TorchHub:
 
         self._cb = _AG(_ag)
         self.net = HubNet(None, world, rank, self._cb)
+
+
+class ShmHub:
+    """cozk_shm_hub: the native shared-memory all-gather of libcozk (csrc/shm_hub.hip) for one-process-per-GPU
+    runs on ONE node.  `group` (a torch.distributed group, any backend) is used only to agree on the segment
+    name and to order create -> attach -> unlink; the per-round exchanges never touch it."""
+    SHM_SYMBOLS = ["cozk_shm_hub_open", "cozk_shm_hub_net", "cozk_shm_hub_unlink", "cozk_shm_hub_set_timeout_ms", "cozk_shm_hub_abort",
+                   "cozk_shm_hub_close"]
+
+    def __init__(self, rank, world, group=None, name=None, slot_bytes=1 << 18, timeout_ms=120000, create=None):
+        import os
+        import secrets
+        self._l = L.lib()
+        l = self._l
+        l.cozk_shm_hub_open.restype = ctypes.c_int
+        l.cozk_shm_hub_open.argtypes = [ctypes.c_char_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(ctypes.c_void_p)]
+        l.cozk_shm_hub_net.restype = ctypes.c_int
+        l.cozk_shm_hub_net.argtypes = [ctypes.c_void_p, ctypes.POINTER(HubNet)]
+        l.cozk_shm_hub_unlink.restype = ctypes.c_int
+        l.cozk_shm_hub_unlink.argtypes = [ctypes.c_void_p]
+        l.cozk_shm_hub_set_timeout_ms.restype = ctypes.c_int
+        l.cozk_shm_hub_set_timeout_ms.argtypes = [ctypes.c_void_p, ctypes.c_uint64]
+        l.cozk_shm_hub_abort.restype = None
+        l.cozk_shm_hub_abort.argtypes = [ctypes.c_void_p]
+        l.cozk_shm_hub_close.restype = None
+        l.cozk_shm_hub_close.argtypes = [ctypes.c_void_p]
+        self.rank, self.world, self.error = rank, world, None
+        self.h = ctypes.c_void_p()
+        use_dist = name is None
+        if use_dist:  # rank 0 picks a fresh name, everyone learns it
+            box = ["/cozk_hub_%d_%s" % (os.getpid(), secrets.token_hex(6))] if rank == 0 else [None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            name = box[0]
+        self.name = name
+        rc = L.OK
+        if create is None:
+            create = rank == 0
+        if create:
+            rc = l.cozk_shm_hub_open(name.encode(), 1, world, rank, slot_bytes, ctypes.byref(self.h))
+        if use_dist:
+            dist.barrier(group=group)
+        if not create:
+            rc = l.cozk_shm_hub_open(name.encode(), 0, world, rank, slot_bytes, ctypes.byref(self.h))
+        if use_dist:
+            dist.barrier(group=group)
+            if rank == 0 and self.h:
+                l.cozk_shm_hub_unlink(self.h)
+        if rc != L.OK:
+            raise L.CozkError(rc, "cozk_shm_hub_open(%s) failed" % name)
+        l.cozk_shm_hub_set_timeout_ms(self.h, timeout_ms)
+        self.net = HubNet()
+        l.cozk_shm_hub_net(self.h, ctypes.byref(self.net))
+
+    def all_gather(self, payload, cap=1 << 18):
+        """byte all-gather through the segment (tests / host code that wants the same transport)"""
+        recv = (ctypes.c_uint8 * (cap * self.world))()
+        lens = (ctypes.c_size_t * self.world)()
+        buf = (ctypes.c_uint8 * max(1, len(payload))).from_buffer_copy(payload or b"\0")
+        rc = self.net.all_gather(self.net.user, ctypes.cast(buf, ctypes.c_void_p), len(payload), ctypes.cast(recv, ctypes.c_void_p), cap, lens)
+        if rc != 0:
+            raise RuntimeError("shm hub all_gather failed (%d)" % rc)
+        raw = bytes(recv)
+        return [raw[i * cap:i * cap + lens[i]] for i in range(self.world)]
+
+    def unlink(self):
+        self._l.cozk_shm_hub_unlink(self.h)
+
+    def abort(self):
+        if self.h:
+            self._l.cozk_shm_hub_abort(self.h)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._l.cozk_shm_hub_close(self.h)
+            self.h = ctypes.c_void_p()
 
 
 class TorchRing:
@@ -161,6 +237,8 @@ class DistributedParty:
         rc = self._l.cozk_harness_prove_distributed(self.h, ctypes.byref(hub.net), ctypes.byref(ring.net) if ring is not None else None,
                                                     1 if verify else 0, ctypes.byref(res))
         if rc != L.OK:
+            if hasattr(hub, "abort"):
+                hub.abort()  # peers blocked in the shared-memory hub fail now instead of timing out
             for t in (hub, ring):
                 if t is not None and t.error is not None:
                     raise t.error

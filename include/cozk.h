@@ -341,6 +341,20 @@ int cozk_harness_create_participant(const cozk_harness_config* cfg, int local_pa
                                     cozk_harness** out);
 int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, const cozk_ring_net* ring,
                                    int verify, cozk_harness_result* res);
+/* Single-node hub: byte all-gather through one POSIX shared-memory segment (lock-free, double-buffered
+ * mailboxes; ~1 us per exchange) for one-process-per-GPU runs on ONE node -- the per-round star messages
+ * (mpc-net/src/mpc_star.rs:29-66) are a few hundred bytes and latency-bound.  Exactly one participant opens
+ * with create = 1 (fails if `name` exists), the others attach with create = 0 afterwards (order the two
+ * with the launcher's barrier); cozk_shm_hub_net fills a cozk_hub_net whose callbacks stay valid until
+ * close.  Waits are bounded (default 120 s, set_timeout_ms) and any participant can abort all of them. */
+typedef struct cozk_shm_hub cozk_shm_hub;
+int cozk_shm_hub_open(const char* name, int create, int n_participants, int my_index, size_t slot_bytes,
+                      cozk_shm_hub** out);
+int cozk_shm_hub_net(cozk_shm_hub* hub, cozk_hub_net* out);
+int cozk_shm_hub_unlink(cozk_shm_hub* hub);
+int cozk_shm_hub_set_timeout_ms(cozk_shm_hub* hub, uint64_t ms);
+void cozk_shm_hub_abort(cozk_shm_hub* hub);
+void cozk_shm_hub_close(cozk_shm_hub* hub);
 /* synchronous raw copy between any two pointers (device or host) on the context's stream: lets a host
  * transport stage ring payloads in buffers of its own (e.g. torch tensors) */
 int cozk_copy(cozk_ctx* ctx, void* dst, const void* src, size_t nbytes);

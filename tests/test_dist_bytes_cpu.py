@@ -36,3 +36,46 @@ def test_all_gather_bytes_gloo_world3(tmp_path):
         out, _ = p.communicate(timeout=300)
         assert p.returncode == 0, out.decode()
         assert b"ok" in out
+
+
+SHM_WORKER = textwrap.dedent("""
+    import importlib, os, sys
+    sys.path.insert(0, %r)
+    rank, world, name = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3]
+    P = importlib.import_module("co-zkvms_amd.party_dist")
+    hub = P.ShmHub(rank, world, name=name, slot_bytes=1 << 17, timeout_ms=60000, create=False)
+    def msg(r, rnd):
+        n = [0, 5, 300, 2040, 70000, 1][(r + rnd) %% 6]
+        return bytes([(r * 7 + rnd * 13 + i) %% 251 for i in range(n)])
+    for rnd in range(400):
+        got = hub.all_gather(msg(rank, rnd), cap=1 << 17)
+        for r in range(world):
+            assert got[r] == msg(r, rnd), (rnd, r, len(got[r]))
+    hub.close()
+    print("rank", rank, "ok")
+""") % ROOT
+
+
+def test_shm_hub_world4(tmp_path):
+    """libcozk's shared-memory hub (csrc/shm_hub.hip): 4 processes, 400 back-to-back variable-length
+    all-gathers (0 B .. 70 kB) -- exercises the double-buffer reuse and the publish/acquire ordering"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    P = importlib.import_module("co-zkvms_amd.party_dist")
+    name = "/cozk_test_%d" % os.getpid()
+    script = tmp_path / "s.py"
+    script.write_text(SHM_WORKER)
+    creator = P.ShmHub(0, 4, name=name, slot_bytes=1 << 17, create=True)  # makes the segment; the 4 children attach to it
+    creator.close()
+    try:
+        procs = [subprocess.Popen([sys.executable, str(script), str(r), "4", name], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+                 for r in range(4)]
+        for p in procs:
+            out, _ = p.communicate(timeout=300)
+            assert p.returncode == 0, out.decode()
+            assert b"ok" in out
+    finally:
+        try:
+            os.unlink("/dev/shm" + name)
+        except OSError:
+            pass
