@@ -161,8 +161,11 @@ class ShmHub:
 class TorchRing:
     """reshare over torch.distributed P2P.  device=None: host staging (gloo); else CUDA staging tensors (nccl/RCCL)"""
 
-    def __init__(self, ctx_handle, rank, world, group=None, device=None):
+    def __init__(self, ctx_handle, rank, world, group=None, device=None, next_rank=None, prev_rank=None):
         self.ctx, self.rank, self.world, self.group, self.device = ctx_handle, rank, world, group, device
+        # ranks (in `group`) of the next / previous party on this ring; default: the whole group is one ring
+        self.next_rank = (rank + 1) % world if next_rank is None else next_rank
+        self.prev_rank = (rank + world - 1) % world if prev_rank is None else prev_rank
         self.error = None
         self._l = L.lib()
         self._l.cozk_copy.restype = ctypes.c_int
@@ -177,7 +180,7 @@ class TorchRing:
                 rbuf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
                 if self._l.cozk_copy(self.ctx, sbuf.data_ptr(), dev_send, nbytes) != 0:
                     return 3
-                nxt, prv = (self.rank + 1) % self.world, (self.rank + self.world - 1) % self.world
+                nxt, prv = self.next_rank, self.prev_rank
                 ops = [dist.P2POp(dist.isend, sbuf, nxt, group=self.group), dist.P2POp(dist.irecv, rbuf, prv, group=self.group)]
                 for req in dist.batch_isend_irecv(ops):
                     req.wait()
