@@ -11,3 +11,4 @@ from .poly import (Rep3DensePolynomial, Rep3DenseInterleavedPolynomial, SplitEqP
                    open_quadratic_evals, pst_fold, prod_sumcheck_evals, spartan_first_round, spartan_second_round,
                    sparse_matvec3)
 from .harness import Harness, HarnessConfig, HarnessResult
+from .spartan import SpartanHarness, SpartanConfig, SpartanResult

@@ -962,3 +962,6 @@ int cozk_worker_spartan_second_sumcheck(cozk_ctx* ctx, const cozk_worker_params*
 }
 
 }  // extern "C"
+
+// --------------------------------------------------------------------------- co-noir-spartan harness (config 4)
+#include "host/spartan_harness.hpp"

@@ -400,16 +400,27 @@ __global__ void __launch_bounds__(PT) k_spartan_second(const fe* __restrict__ za
 
 // zero_round (co-noir-spartan/co-spartan/src/worker.rs:153-182): za[row] = sum_nnz val_a * z[col] (same for
 // b, c) on shares, CSR rows (field sums are order-independent, so COO vs CSR order cannot change a bit)
+// Rows up to SPMV_LONG entries: one lane per row.  Longer rows (R1CS has them: the constant-1 column of the
+// transposed matrices that `third_round` walks, worker.rs:241-249, holds an entry of almost every constraint)
+// are queued on the device and reduced by one workgroup each in k_sparse_matvec3_long, so a dense row/column
+// costs a block-wide tree sum instead of a 2^18-step serial loop.
+static constexpr uint32_t SPMV_LONG = 64;
 template <int NC>
 __global__ void __launch_bounds__(PT) k_sparse_matvec3(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                     const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
                                                     const fe* __restrict__ za, const fe* __restrict__ zb, size_t nrows,
-                                                    fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1) {
+                                                    fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1,
+                                                    uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_rows) {
     size_t r = (size_t)blockIdx.x * PT + threadIdx.x;
     if (r >= nrows) return;
+    uint32_t e0 = row_ptr[r], e1 = row_ptr[r + 1];
+    if (e1 - e0 > SPMV_LONG) {
+        long_rows[atomicAdd(long_count, 1u)] = (uint32_t)r;
+        return;
+    }
     Sh<NC> A, B, C;
     for (int k = 0; k < NC; k++) A.c[k] = B.c[k] = C.c[k] = Fr::zero();
-    for (uint32_t e = row_ptr[r]; e < row_ptr[r + 1]; e++) {
+    for (uint32_t e = e0; e < e1; e++) {
         Sh<NC> z = sh_load<NC>(za, zb, col[e]);
         A = sh_add<NC>(A, sh_mul_public<NC>(z, fe_load(va + e)));
         B = sh_add<NC>(B, sh_mul_public<NC>(z, fe_load(vb + e)));
@@ -418,6 +429,36 @@ __global__ void __launch_bounds__(PT) k_sparse_matvec3(const uint32_t* __restric
     sh_store<NC>(oa0, oa1, r, A);
     sh_store<NC>(ob0, ob1, r, B);
     sh_store<NC>(oc0, oc1, r, C);
+}
+template <int NC>
+__global__ void __launch_bounds__(PT) k_sparse_matvec3_long(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                         const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
+                                                         const fe* __restrict__ za, const fe* __restrict__ zb,
+                                                         fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1,
+                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_rows) {
+    __shared__ fe sh4[4];
+    uint32_t nlong = *long_count;
+    for (uint32_t q = blockIdx.x; q < nlong; q += gridDim.x) {  // every workgroup reaches the end of the queue
+        uint32_t r = long_rows[q];
+        Sh<NC> A, B, C;
+        for (int k = 0; k < NC; k++) A.c[k] = B.c[k] = C.c[k] = Fr::zero();
+        for (uint32_t e = row_ptr[r] + threadIdx.x; e < row_ptr[r + 1]; e += PT) {
+            Sh<NC> z = sh_load<NC>(za, zb, col[e]);
+            A = sh_add<NC>(A, sh_mul_public<NC>(z, fe_load(va + e)));
+            B = sh_add<NC>(B, sh_mul_public<NC>(z, fe_load(vb + e)));
+            C = sh_add<NC>(C, sh_mul_public<NC>(z, fe_load(vc + e)));
+        }
+        for (int k = 0; k < NC; k++) {
+            A.c[k] = fr_block_sum(A.c[k], sh4);
+            B.c[k] = fr_block_sum(B.c[k], sh4);
+            C.c[k] = fr_block_sum(C.c[k], sh4);
+        }
+        if (threadIdx.x == 0) {
+            sh_store<NC>(oa0, oa1, r, A);
+            sh_store<NC>(ob0, ob1, r, B);
+            sh_store<NC>(oc0, oc1, r, C);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ kernels: split-eq tables
@@ -966,12 +1007,26 @@ int cozk_sparse_matvec3(cozk_ctx* ctx, const cozk_vec* row_ptr, const cozk_vec* 
             o[i]->a0 = dev_alloc_fe(nrows);
             o[i]->b0 = z->mode == COZK_MODE_REP3 ? dev_alloc_fe(nrows) : nullptr;
         }
-        if (z->mode == COZK_MODE_REP3)
-            k_sparse_matvec3<2><<<grid_for(nrows), PT, 0, ctx->stream>>>((const uint32_t*)row_ptr->d, (const uint32_t*)col->d, (const fe*)val_a->d, (const fe*)val_b->d,
-                                                                        (const fe*)val_c->d, poly_a(z), poly_b(z), nrows, o[0]->a0, o[0]->b0, o[1]->a0, o[1]->b0, o[2]->a0, o[2]->b0);
-        else
-            k_sparse_matvec3<1><<<grid_for(nrows), PT, 0, ctx->stream>>>((const uint32_t*)row_ptr->d, (const uint32_t*)col->d, (const fe*)val_a->d, (const fe*)val_b->d,
-                                                                        (const fe*)val_c->d, poly_a(z), nullptr, nrows, o[0]->a0, nullptr, o[1]->a0, nullptr, o[2]->a0, nullptr);
+        // device-side queue of the rows longer than SPMV_LONG (count + indices) in the context scratch
+        ctx->scratch.reserve((nrows + 16) * sizeof(uint32_t));
+        uint32_t* lcount = ctx->scratch.as<uint32_t>();
+        uint32_t* lrows = lcount + 16;
+        HIP_TRY(hipMemsetAsync(lcount, 0, sizeof(uint32_t), ctx->stream));
+        const uint32_t* rp = (const uint32_t*)row_ptr->d;
+        const uint32_t* ci = (const uint32_t*)col->d;
+        const fe *pa = (const fe*)val_a->d, *pb = (const fe*)val_b->d, *pc = (const fe*)val_c->d;
+        unsigned glong = (unsigned)std::min<size_t>(nrows, 1024);
+        if (z->mode == COZK_MODE_REP3) {
+            k_sparse_matvec3<2><<<grid_for(nrows), PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), poly_b(z), nrows, o[0]->a0, o[0]->b0, o[1]->a0,
+                                                                        o[1]->b0, o[2]->a0, o[2]->b0, lcount, lrows);
+            k_sparse_matvec3_long<2><<<glong, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), poly_b(z), o[0]->a0, o[0]->b0, o[1]->a0, o[1]->b0, o[2]->a0,
+                                                                   o[2]->b0, lcount, lrows);
+        } else {
+            k_sparse_matvec3<1><<<grid_for(nrows), PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), nullptr, nrows, o[0]->a0, nullptr, o[1]->a0, nullptr,
+                                                                        o[2]->a0, nullptr, lcount, lrows);
+            k_sparse_matvec3_long<1><<<glong, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), nullptr, o[0]->a0, nullptr, o[1]->a0, nullptr, o[2]->a0, nullptr,
+                                                                   lcount, lrows);
+        }
         HIP_TRY(hipGetLastError());
         *out_za = o[0];
         *out_zb = o[1];

@@ -360,6 +360,34 @@ void cozk_shm_hub_close(cozk_shm_hub* hub);
 int cozk_copy(cozk_ctx* ctx, void* dst, const void* src, size_t nbytes);
 cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party);
 
+/* ---------------------------------------------------------------- co-noir-spartan harness ---- */
+/* BASELINE config 4 restated: a satisfied synthetic R1CS with 2^log_n constraints and
+ * variables, 3 entries per row shared by A, B, C; worker side of SpartanProverWorker::prove
+ * (co-noir-spartan/co-spartan/src/worker.rs:119-300): zero_round, PST commit of z, first (degree-3) and
+ * second (degree-2) sumcheck, z(ry), distributed_open; the calling thread is coordinator + verifier.
+ * MODE_REP3 runs three parties (devices[p]); MODE_PLAIN one. */
+typedef struct cozk_spartan cozk_spartan;
+typedef struct cozk_spartan_config {
+    int mode;
+    int log_n;
+    int precompute; /* window table for the SRS (as cozk_harness_config) */
+    int devices[3];
+    uint64_t seed;
+} cozk_spartan_config;
+typedef struct cozk_spartan_result {
+    int verified; /* 1 ok, 0 rejected, -1 not run */
+    double wall_ms;
+    double t_zero_round_ms, t_commit_ms, t_sumcheck1_ms, t_matrix_build_ms, t_sumcheck2_ms, t_open_ms, t_worker_ms;
+    uint64_t bytes_star_up, bytes_star_down, star_messages;
+    uint64_t proof_len;
+    uint8_t proof_digest[32]; /* SHA-256 of the serialized proof */
+} cozk_spartan_result;
+int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out);
+const char* cozk_spartan_error(const cozk_spartan* h);
+int cozk_spartan_destroy(cozk_spartan* h);
+int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res);
+int cozk_spartan_proof_bytes(const cozk_spartan* h, uint8_t* out, size_t cap);
+
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation, k_msm_accum0) on the ctx stream,
  * for bench.py's roofline object: launches, total ms, point additions issued, and the algorithmic

@@ -1,0 +1,158 @@
+"""
+ORACLE (test infrastructure, NOT product code) -- pure-Python restatement of the co-noir-spartan pipeline
+that co-zkvms_amd/csrc/host/spartan_harness.hpp runs on the GPU (BASELINE config 4): same
+seeded satisfied R1CS, same message schedule, same SHA-256 transcript, same proof serialisation.  Run in
+the clear: every value that enters the proof is a sum over the parties' shares, in which shares and masks
+cancel, so the plain run pins both the plain and the 3-party Rep3 HIP runs.  Parity unpinned by reference
+outputs (the reference is Rust and holds no vectors for this path); pinned by the verifier identities and by
+agreeing bit for bit with the independent HIP implementation.
+
+Reference call chain restated: co-noir-spartan/co-spartan/src/worker.rs:119-300 (zero_round, first_round,
+second_round, third_round), sumcheck.rs:171-395 (round functions), worker.rs:774-809 (distributed_open).
+"""
+import hashlib
+
+import pyref as O
+
+R = O.R
+
+
+def _ser_fr(x):
+    return (x % R).to_bytes(32, "little")
+
+
+def _ser_u64(x):
+    return int(x).to_bytes(8, "little")
+
+
+def _ser_vec(v):
+    return _ser_u64(len(v)) + b"".join(_ser_fr(x) for x in v)
+
+
+def _ser_g1(pt):
+    if pt is None:
+        return b"\x00" * 63 + b"\x40"
+    return pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+
+
+def eq_le(r):
+    """generate_eq: out[idx] = prod_i (bit i of idx ? r_i : 1 - r_i)"""
+    t = [1]
+    for ri in r:
+        t = [x * (1 - ri) % R for x in t] + [x * ri % R for x in t]
+    return t
+
+
+def fix_low(v, r):
+    """DenseMultilinearExtension::fix_variables(&[r]) / Rep3DensePolynomial::fix_variables
+    (mpc-core/src/protocols/rep3/poly.rs:56-62): binds variable 0"""
+    return [(v[2 * b] + r * (v[2 * b + 1] - v[2 * b])) % R for b in range(len(v) // 2)]
+
+
+def eval_points(ev, r):
+    """value at r of the polynomial through (i, ev[i])"""
+    return O.unipoly_eval(O.unipoly_from_evals(ev), r)
+
+
+def build_instance(seed, nv):
+    n = 1 << nv
+    z = O.synthetic_fr(seed + 1000, n)
+    z[0] = 1
+    cols = O.synthetic_small(seed + 7000, 3 * n, nv)
+    va = O.synthetic_fr(seed + 7100, 3 * n)
+    vb = O.synthetic_fr(seed + 7200, 3 * n)
+    vc = O.synthetic_fr(seed + 7300, 3 * n)
+    entries = []  # (row, col, a, b, c)
+    for i in range(n):
+        az = bz = cz = 0
+        for k in range(3):
+            e = 3 * i + k
+            cj = cols[e] if k < 2 else 0
+            az = (az + va[e] * z[cj]) % R
+            bz = (bz + vb[e] * z[cj]) % R
+            if k < 2:
+                c = vc[e]
+                cz = (cz + c * z[cj]) % R
+            else:
+                c = (az * bz - cz) % R
+            entries.append((i, cj, va[e], vb[e], c))
+    return z, entries
+
+
+def run(cfg):
+    """cfg: dict(log_n, seed).  Returns dict(proof_bytes, digest, verified)."""
+    nv, seed = cfg["log_n"], cfg["seed"]
+    n = 1 << nv
+    z, entries = build_instance(seed, nv)
+    t = O.synthetic_fr(seed ^ 0x7A7A7A7A, nv)
+    powers = []
+    for i in range(nv):
+        ev = [1]
+        for tj in t[i:]:
+            ev = [e * (1 - tj) % R for e in ev] + [e * tj % R for e in ev]
+        powers.append([O.g1_mul(O.G1_GEN, e) for e in ev])
+    ck = {"nv": nv, "t": t, "g": O.G1_GEN, "powers_of_g": powers}
+    # zero_round
+    za = O.sparse_matvec([(r_, c_, a_) for r_, c_, a_, _, _ in entries], z, n)
+    zb = O.sparse_matvec([(r_, c_, b_) for r_, c_, _, b_, _ in entries], z, n)
+    zc = O.sparse_matvec([(r_, c_, c2) for r_, c_, _, _, c2 in entries], z, n)
+    assert all((x * y - w) % R == 0 for x, y, w in zip(za, zb, zc)), "synthetic R1CS not satisfied"
+    # first_round
+    cz = O.pst_commit(ck, z)
+    tr = O.Transcript(b"cozk-spartan")
+    tr.append_point(cz)
+    tau = tr.challenge_vector(nv)
+    # second_round: degree-3 sumcheck of eq * (za zb - zc)
+    eq = eq_le(tau)
+    ok = True
+    claim = 0
+    sc1, rx = [], []
+    for _ in range(nv):
+        ev = O.spartan_first_round_evals(za, zb, zc, eq)
+        ok &= (ev[0] + ev[1]) % R == claim
+        tr.append_scalars(ev)
+        r = tr.challenge_scalar()
+        sc1.append(ev)
+        rx.append(r)
+        claim = eval_points(ev, r)
+        za, zb, zc, eq = fix_low(za, r), fix_low(zb, r), fix_low(zc, r), fix_low(eq, r)
+    fin1 = [za[0], zb[0], zc[0], eq[0]]
+    ok &= claim == fin1[3] * (fin1[0] * fin1[1] - fin1[2]) % R
+    tr.append_scalars(fin1[:3])
+    abc = tr.challenge_vector(3)
+    # third_round: A(rx, .), B(rx, .), C(rx, .), degree-2 sumcheck of z * (alpha A + beta B + gamma C)
+    eq_rx = eq_le(rx)
+    arx, brx, crx = [0] * n, [0] * n, [0] * n
+    for row, col, a_, b_, c_ in entries:
+        arx[col] = (arx[col] + a_ * eq_rx[row]) % R
+        brx[col] = (brx[col] + b_ * eq_rx[row]) % R
+        crx[col] = (crx[col] + c_ * eq_rx[row]) % R
+    claim2 = (abc[0] * fin1[0] + abc[1] * fin1[1] + abc[2] * fin1[2]) % R
+    zw = list(z)
+    sc2, ry = [], []
+    for _ in range(nv):
+        ev = O.spartan_second_round_evals(zw, arx, brx, crx, abc)
+        ok &= (ev[0] + ev[1]) % R == claim2
+        tr.append_scalars(ev)
+        r = tr.challenge_scalar()
+        sc2.append(ev)
+        ry.append(r)
+        claim2 = eval_points(ev, r)
+        zw, arx, brx, crx = fix_low(zw, r), fix_low(arx, r), fix_low(brx, r), fix_low(crx, r)
+    fin2 = [zw[0], arx[0], brx[0], crx[0]]
+    ok &= claim2 == fin2[0] * (abc[0] * fin2[1] + abc[1] * fin2[2] + abc[2] * fin2[3]) % R
+    z_eval = O.pst_evaluate_le(z, ry)
+    ok &= z_eval == fin2[0]
+    # the verifier's own matrix evaluations
+    eq_ry = eq_le(ry)
+    sa = sum(a_ * eq_rx[row] * eq_ry[col] for row, col, a_, _, _ in entries) % R
+    ok &= sa == fin2[1]
+    # distributed_open: no reversal, point[i] folds variable i
+    proofs, val = O.pst_open(ck, z, ry)
+    ok &= val == z_eval
+    ok &= O.pst_check_with_trapdoor(ck, cz, ry, z_eval, proofs)
+    blob = _ser_u64(nv) + _ser_g1(cz)
+    blob += _ser_u64(len(sc1)) + b"".join(_ser_vec(e) for e in sc1) + _ser_vec(fin1)
+    blob += _ser_u64(len(sc2)) + b"".join(_ser_vec(e) for e in sc2) + _ser_vec(fin2)
+    blob += _ser_fr(z_eval) + _ser_u64(len(proofs)) + b"".join(_ser_g1(p) for p in proofs)
+    return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": bool(ok)}

@@ -125,3 +125,14 @@ def test_pipeline_c_equals_python_equals_golden():
     # the Python pipeline regenerates the first fixture (slow path, one config)
     cfg = GOLD["pipelines"][0]["cfg"]
     assert pyharness.run(cfg)["digest"] == GOLD["pipelines"][0]["digest"]
+
+
+def test_spartan_pipeline_oracle_self_consistent():
+    """oracle/pyspartan.py: the synthetic R1CS is satisfied, both sumchecks, the matrix evaluation and the PST13
+    opening verify; the digest is deterministic in the seed"""
+    import pyspartan
+    a = pyspartan.run(dict(log_n=4, seed=11))
+    b = pyspartan.run(dict(log_n=4, seed=11))
+    c = pyspartan.run(dict(log_n=4, seed=12))
+    assert a["verified"] and c["verified"]
+    assert a["digest"] == b["digest"] != c["digest"]
