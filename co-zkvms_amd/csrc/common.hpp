@@ -69,6 +69,8 @@ struct cozk_ctx {
     DevBuf scratch2;
     void* pinned = nullptr;  // pinned host staging for small D2H results
     size_t pinned_cap = 0;
+    uint32_t* msm_pinned = nullptr;  // largest bucket of the current MSM launch set (read back behind an event)
+    hipEvent_t msm_event = nullptr;
     // timing of the dominant kernel (bench roofline): accumulated HIP-event time of the
     // bucket-accumulation launches on this stream
     bool prof_enabled = false;

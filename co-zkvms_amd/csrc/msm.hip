@@ -355,6 +355,14 @@ __global__ void __launch_bounds__(1024) k_scan(const uint32_t* in, uint32_t nb, 
     if (tid == 1023) off[nb] = sh[1023];
 }
 
+// *out = max(*out, max_i v[i]): the fullest bucket of a launch set decides how many fold levels it needs
+__global__ void __launch_bounds__(256) k_max_u32(const uint32_t* __restrict__ v, uint32_t n, uint32_t* __restrict__ out) {
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) m = max(m, v[i]);
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_down((int)m, o));
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+
 // largest b with off[b] <= t (buckets without segments are skipped automatically)
 static __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint32_t nb, uint32_t t) {
     uint32_t lo = 0, hi = nb;
@@ -585,9 +593,12 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
     uint32_t L0 = (uint32_t)(M >> 18);
     if (L0 < 8) L0 = 8;
     if (L0 > 64) L0 = 64;
-    const uint32_t L1 = 64;
+    // upper levels fold <= L1 partial sums per lane.  The chain is serial (a full XYZZ addition per step, ~25 us
+    // when a wave runs alone), so it is kept short: 64-long chains made the fold of the one heavy bucket of a
+    // u16 / u32 / flag column (the carry digit: n/2 references) cost as much as its whole gather pass.
+    const uint32_t L1 = 8;
 
-    ws.hist.reserve((size_t)(nb + 1) * 4);
+    ws.hist.reserve((size_t)(nb + 2) * 4);
     ws.off0.reserve((size_t)(nb + 1) * 4);
     ws.offA.reserve((size_t)(nb + 1) * 4);
     ws.offB.reserve((size_t)(nb + 1) * 4);
@@ -616,7 +627,17 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
             k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
         }
     };
-    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 1) * 4, st));
+    HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 2) * 4, st));
+    uint32_t* d_maxcnt = hist + nb + 1;  // not touched by the scans (they own hist[0..nb])
+    if (!ctx->msm_pinned) HIP_TRY(hipHostMalloc((void**)&ctx->msm_pinned, 64, hipHostMallocDefault));
+    if (!ctx->msm_event) HIP_TRY(hipEventCreateWithFlags(&ctx->msm_event, hipEventDisableTiming));
+    // after the histogram: fullest bucket -> pinned host word, behind an event the host waits on only when it
+    // sizes the fold levels (by then the GPU is inside the long gather pass, so the queue never drains)
+    auto read_back_max = [&] {
+        k_max_u32<<<std::min<uint32_t>(cdiv(nb, 256), 1024u), 256, 0, st>>>(hist, nb, d_maxcnt);
+        HIP_TRY(hipMemcpyAsync(ctx->msm_pinned, d_maxcnt, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(ctx->msm_event, st));
+    };
     if (pre) {
         // LDS-privatised counting sort: one launch per scalar kind, grid = (workgroups per polynomial, polynomials)
         std::vector<MsmPolyDesc> descs;
@@ -640,6 +661,7 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
             dim3 grid(wgs, r.second.second);
             KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist)));
         }
+        read_back_max();
         scan(false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
@@ -650,6 +672,7 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
             uint32_t* h = hist + (size_t)p * G * NB;
             if (ns[p]) KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], ns[p], h, 1));
         }
+        read_back_max();
         scan(false, hist, 1, off0, hist);
         for (size_t p = 0; p < P; p++) {
             uint32_t* cur = hist + (size_t)p * G * NB;
@@ -675,8 +698,11 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
         ctx->prof_units += M;
         for (size_t p = 0; p < P; p++) ctx->prof_alg_bytes += (uint64_t)ns[p] * (64 + scalar_kind_bytes(kinds[p]));
     }
-    // further levels until the worst case leaves one value per bucket
-    uint64_t cnt = (bound + L0 - 1) / L0;
+    // further levels until the fullest bucket is down to one value
+    HIP_TRY(hipEventSynchronize(ctx->msm_event));
+    uint64_t fullest = *(volatile uint32_t*)ctx->msm_pinned;
+    COZK_REQUIRE(fullest <= bound, "msm: histogram larger than the reference count");
+    uint64_t cnt = (fullest + L0 - 1) / L0;
     uint64_t maxseg = maxseg0;
     g1_xyzz* cur_items = ws.partA.as<g1_xyzz>();
     g1_xyzz* nxt_items = ws.partB.as<g1_xyzz>();
