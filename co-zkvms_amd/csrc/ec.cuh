@@ -98,9 +98,7 @@ struct G1 {
         Fq::mul2(Pd, PP, p.x, PP, PPP, Q);
         g1_xyzz r;
         r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
-        fe t1, t2;
-        Fq::mul2(Rd, Fq::sub(Q, r.x), p.y, PPP, t1, t2);
-        r.y = Fq::sub(t1, t2);
+        r.y = Fq::mul_sub2(Rd, Fq::sub(Q, r.x), p.y, PPP);  // one Montgomery reduction for both products
         Fq::mul2(p.zz, PP, p.zzz, PPP, r.zz, r.zzz);
         return r;
     }
@@ -123,9 +121,7 @@ struct G1 {
         Fq::mul2(Pd, PP, U1, PP, PPP, Q);
         g1_xyzz r;
         r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
-        fe t1, t2;
-        Fq::mul2(Rd, Fq::sub(Q, r.x), S1, PPP, t1, t2);
-        r.y = Fq::sub(t1, t2);
+        r.y = Fq::mul_sub2(Rd, Fq::sub(Q, r.x), S1, PPP);
         fe zz12, zzz12;
         Fq::mul2(p.zz, q.zz, p.zzz, q.zzz, zz12, zzz12);
         Fq::mul2(zz12, PP, zzz12, PPP, r.zz, r.zzz);
