@@ -2,9 +2,11 @@
 //
 // Bucket accumulators use extended-Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
 // mixed addition of an affine SRS point costs 8M + 2S with no inversion, full addition 12M + 2S.
-// All field values are kept fully reduced so that the P == Q / P == -Q special cases can be
-// detected by limb comparison; every formula handles identity, doubling and cancellation, because
-// bucket contents arrive in arbitrary (atomic-scatter) order and SRS points may repeat.
+// XYZZ coordinates live in the lazy range [0, 2p) on the device (ff.cuh l-operations: products skip their
+// final conditional subtraction); affine points are always canonical, and to_affine canonicalises.  The
+// P == Q / P == -Q special cases are detected by a zero test that accepts 0 and p; every formula handles
+// identity, doubling and cancellation, because bucket contents arrive in arbitrary (atomic-scatter) order
+// and SRS points may repeat.
 // Result convention at the C ABI: affine, Montgomery, LE limbs -- what `into_affine()` yields at
 // co-jolt/src/poly/commitment/pst13.rs:294,328.
 #pragma once
@@ -45,7 +47,7 @@ struct G1 {
     }
     static FF_HD g1_xyzz neg(const g1_xyzz& p) {
         g1_xyzz r = p;
-        r.y = Fq::neg(p.y);
+        r.y = Fq::lneg(p.y);
         return r;
     }
     // 2*(x, y) for an affine point (EFD mdbl-2008-s-1, a = 0)
@@ -64,67 +66,67 @@ struct G1 {
         r.zzz = W;
         return r;
     }
-    // 2*P (EFD dbl-2008-s-1, a = 0)
+    // 2*P (EFD dbl-2008-s-1, a = 0), lazy range in and out
     static FF_HD g1_xyzz dbl(const g1_xyzz& p) {
-        if (is_identity(p) || Fq::is_zero(p.y)) return identity();
-        fe U = Fq::dbl(p.y);
-        fe V = Fq::sqr(U);
-        fe W = Fq::mul(U, V);
-        fe S = Fq::mul(p.x, V);
-        fe XX = Fq::sqr(p.x);
-        fe M = Fq::add(Fq::dbl(XX), XX);
+        if (is_identity(p) || Fq::lis_zero(p.y)) return identity();
+        fe U = Fq::ldbl(p.y);
+        fe V = Fq::lmul(U, U);
+        fe W, S;
+        Fq::lmul2(U, V, p.x, V, W, S);
+        fe XX = Fq::lmul(p.x, p.x);
+        fe M = Fq::ladd(Fq::ldbl(XX), XX);
         g1_xyzz r;
-        r.x = Fq::sub(Fq::sqr(M), Fq::dbl(S));
-        r.y = Fq::sub(Fq::mul(M, Fq::sub(S, r.x)), Fq::mul(W, p.y));
-        r.zz = Fq::mul(V, p.zz);
-        r.zzz = Fq::mul(W, p.zzz);
+        r.x = Fq::lsub(Fq::lmul(M, M), Fq::ldbl(S));
+        r.y = Fq::lmul_sub2(M, Fq::lsub(S, r.x), W, p.y);
+        Fq::lmul2(V, p.zz, W, p.zzz, r.zz, r.zzz);
         return r;
     }
-    // P + Q, Q affine (EFD madd-2008-s).  The ten products are issued as five independent pairs (mul2).
+    // P + Q, Q affine and canonical (EFD madd-2008-s): ten products as four independent pairs (lmul2) plus Y3's
+    // two under one reduction; no product pays its final conditional subtraction (lazy range)
     static FF_HD g1_xyzz add_mixed(const g1_xyzz& p, const g1_affine& q) {
         if (is_inf(q)) return p;
         if (is_identity(p)) return from_affine(q);
         fe U2, S2;
-        Fq::mul2(q.x, p.zz, q.y, p.zzz, U2, S2);
-        fe Pd = Fq::sub(U2, p.x);
-        fe Rd = Fq::sub(S2, p.y);
-        if (Fq::is_zero(Pd)) {
-            if (Fq::is_zero(Rd)) return dbl_affine(q);
+        Fq::lmul2(q.x, p.zz, q.y, p.zzz, U2, S2);
+        fe Pd = Fq::lsub(U2, p.x);
+        fe Rd = Fq::lsub(S2, p.y);
+        if (Fq::lis_zero(Pd)) {
+            if (Fq::lis_zero(Rd)) return dbl_affine(q);
             return identity();
         }
         fe PP, RR;
-        Fq::mul2(Pd, Pd, Rd, Rd, PP, RR);
+        Fq::lmul2(Pd, Pd, Rd, Rd, PP, RR);
         fe PPP, Q;
-        Fq::mul2(Pd, PP, p.x, PP, PPP, Q);
+        Fq::lmul2(Pd, PP, p.x, PP, PPP, Q);
         g1_xyzz r;
-        r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
-        r.y = Fq::mul_sub2(Rd, Fq::sub(Q, r.x), p.y, PPP);  // one Montgomery reduction for both products
-        Fq::mul2(p.zz, PP, p.zzz, PPP, r.zz, r.zzz);
+        r.x = Fq::lsub(Fq::lsub(RR, PPP), Fq::ldbl(Q));
+        r.y = Fq::lmul_sub2(Rd, Fq::lsub(Q, r.x), p.y, PPP);
+        Fq::lmul2(p.zz, PP, p.zzz, PPP, r.zz, r.zzz);
         return r;
     }
-    // P + Q (EFD add-2008-s): 14 products as seven independent pairs
+    // P + Q (EFD add-2008-s): 14 products, lazy range in and out
     static FF_HD g1_xyzz add(const g1_xyzz& p, const g1_xyzz& q) {
         if (is_identity(q)) return p;
         if (is_identity(p)) return q;
         fe U1, U2, S1, S2;
-        Fq::mul2(p.x, q.zz, q.x, p.zz, U1, U2);
-        Fq::mul2(p.y, q.zzz, q.y, p.zzz, S1, S2);
-        fe Pd = Fq::sub(U2, U1);
-        fe Rd = Fq::sub(S2, S1);
-        if (Fq::is_zero(Pd)) {
-            if (Fq::is_zero(Rd)) return dbl(p);
+        Fq::lmul2(p.x, q.zz, q.x, p.zz, U1, U2);
+        Fq::lmul2(p.y, q.zzz, q.y, p.zzz, S1, S2);
+        fe Pd = Fq::lsub(U2, U1);
+        fe Rd = Fq::lsub(S2, S1);
+        if (Fq::lis_zero(Pd)) {
+            if (Fq::lis_zero(Rd)) return dbl(p);
             return identity();
         }
         fe PP, RR;
-        Fq::mul2(Pd, Pd, Rd, Rd, PP, RR);
+        Fq::lmul2(Pd, Pd, Rd, Rd, PP, RR);
         fe PPP, Q;
-        Fq::mul2(Pd, PP, U1, PP, PPP, Q);
+        Fq::lmul2(Pd, PP, U1, PP, PPP, Q);
         g1_xyzz r;
-        r.x = Fq::sub(Fq::sub(RR, PPP), Fq::dbl(Q));
-        r.y = Fq::mul_sub2(Rd, Fq::sub(Q, r.x), S1, PPP);
+        r.x = Fq::lsub(Fq::lsub(RR, PPP), Fq::ldbl(Q));
+        r.y = Fq::lmul_sub2(Rd, Fq::lsub(Q, r.x), S1, PPP);
         fe zz12, zzz12;
-        Fq::mul2(p.zz, q.zz, p.zzz, q.zzz, zz12, zzz12);
-        Fq::mul2(zz12, PP, zzz12, PPP, r.zz, r.zzz);
+        Fq::lmul2(p.zz, q.zz, p.zzz, q.zzz, zz12, zzz12);
+        Fq::lmul2(zz12, PP, zzz12, PPP, r.zz, r.zzz);
         return r;
     }
     // affine = (X/ZZ, Y/ZZZ); one field inversion: 1/ZZZ, then 1/ZZ = ZZ^2 / ZZZ^2 ... computed as
@@ -136,11 +138,12 @@ struct G1 {
             r.y = Fq::zero();
             return r;
         }
-        fe t = Fq::inv(Fq::mul(p.zz, p.zzz));
-        fe izz = Fq::mul(t, p.zzz);
-        fe izzz = Fq::mul(t, p.zz);
-        r.x = Fq::mul(p.x, izz);
-        r.y = Fq::mul(p.y, izzz);
+        fe zz = Fq::lcanon(p.zz), zzz = Fq::lcanon(p.zzz);
+        fe t = Fq::inv(Fq::mul(zz, zzz));
+        fe izz = Fq::mul(t, zzz);
+        fe izzz = Fq::mul(t, zz);
+        r.x = Fq::mul(Fq::lcanon(p.x), izz);
+        r.y = Fq::mul(Fq::lcanon(p.y), izzz);
         return r;
     }
     static FF_HD bool on_curve(const g1_affine& p) {

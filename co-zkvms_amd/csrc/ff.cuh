@@ -140,6 +140,15 @@ struct Field {
     // 128 mads + 122 64-bit adds + 333 moves for what hipcc makes of the portable CIOS.
     static FF_HD fe mul(const fe& a, const fe& b) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        return reduce_once(mul_nr(a, b));
+#else
+        return mul_host(a, b);
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the product before its final conditional subtraction: for inputs < 2 MOD the result is < MOD (1 + 4 MOD / R)
+    // < 1.76 MOD (R = 2^256, MOD < 2^254), i.e. again < 2 MOD -- the "lazy" range the EC formulas work in
+    static __device__ __forceinline__ fe mul_nr(const fe& a, const fe& b) {
         uint64_t lo = 0;
         uint32_t hi = 0;
         uint32_t m[8], r[8];
@@ -199,8 +208,10 @@ struct Field {
         fe o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.l[i] = r[i];
-        return reduce_once(o);
-#else
+        return o;
+    }
+#endif
+    static inline fe mul_host(const fe& a, const fe& b) {
         uint32_t t[8];
         for (int i = 0; i < 8; i++) t[i] = 0;
         for (int i = 0; i < 8; i++) {
@@ -221,7 +232,6 @@ struct Field {
         fe r;
         for (int i = 0; i < 8; i++) r.l[i] = t[i];
         return reduce_once(r);
-#endif
     }
     static FF_HD fe sqr(const fe& a) { return mul(a, a); }
     // (a*b + c*d) * R^-1 mod MOD with ONE Montgomery reduction: both products accumulate into the same column
@@ -230,6 +240,15 @@ struct Field {
     // two separate products + an addition: used for Y3 = R (Q - X3) - Y1 PPP of the XYZZ additions.
     static FF_HD fe mul_add2(const fe& a, const fe& b, const fe& c, const fe& d) {
 #if defined(__HIP_DEVICE_COMPILE__)
+        return reduce_once(mul_add2_nr(a, b, c, d));
+#else
+        return add(mul(a, b), mul(c, d));
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // before the final subtraction: < MOD (1 + 2 MOD / R) for canonical inputs, < MOD (1 + 8 MOD / R) < 2.52 MOD for
+    // inputs < 2 MOD
+    static __device__ __forceinline__ fe mul_add2_nr(const fe& a, const fe& b, const fe& c, const fe& d) {
         uint64_t lo = 0;
         uint32_t hi = 0;
         uint32_t m[8], r[8];
@@ -306,11 +325,9 @@ struct Field {
         fe o;
 #pragma unroll
         for (int i = 0; i < 8; i++) o.l[i] = r[i];
-        return reduce_once(o);
-#else
-        return add(mul(a, b), mul(c, d));
-#endif
+        return o;
     }
+#endif
     // a*b - c*d with one reduction
     static FF_HD fe mul_sub2(const fe& a, const fe& b, const fe& c, const fe& d) { return mul_add2(a, b, neg(c), d); }
 
@@ -338,6 +355,150 @@ struct Field {
 #else
         o1 = mul(a, b);
         o2 = mul(c, d);
+#endif
+    }
+
+    // ---- lazy range [0, 2 MOD) for the EC formulas (device): products skip their final conditional subtraction
+    // (16 of ~330 instructions each), additions / subtractions correct by 2 MOD instead of MOD, zero tests accept
+    // 0 and MOD.  4 MOD < 2^256, so nothing overflows.  On the host these are the canonical operations (values
+    // agree mod MOD; only canonical results -- to_affine -- are ever compared or serialised).
+    static FF_HD fe two_mod() {
+        fe r;
+        uint32_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            r.l[i] = (Pm::MOD[i] << 1) | c;
+            c = Pm::MOD[i] >> 31;
+        }
+        return r;
+    }
+    static FF_HD fe lcanon(const fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return reduce_once(a);
+#else
+        return a;
+#endif
+    }
+    static FF_HD fe lmul(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return mul_nr(a, b);
+#else
+        return mul(a, b);
+#endif
+    }
+    static FF_HD void lmul2(const fe& a, const fe& b, const fe& c, const fe& d, fe& o1, fe& o2) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint64_t lo1 = 0, lo2 = 0;
+        uint32_t hi1 = 0, hi2 = 0;
+        uint32_t m1[8], m2[8], r1[8], r2[8];
+        const uint32_t* A = a.l;
+        const uint32_t* B = b.l;
+        const uint32_t* C = c.l;
+        const uint32_t* D = d.l;
+        FF_MUL2_BODY
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            o1.l[i] = r1[i];
+            o2.l[i] = r2[i];
+        }
+#else
+        o1 = mul(a, b);
+        o2 = mul(c, d);
+#endif
+    }
+    static FF_HD fe ladd(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        fe s;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.l[i] + b.l[i] + c;
+            s.l[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+        const fe tm = two_mod();
+        fe d;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)s.l[i] - tm.l[i] - borrow;
+            d.l[i] = (uint32_t)t;
+            borrow = (t >> 63) & 1;
+        }
+        fe r;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r.l[i] = borrow ? s.l[i] : d.l[i];
+        return r;
+#else
+        return add(a, b);
+#endif
+    }
+    static FF_HD fe lsub(const fe& a, const fe& b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        fe d;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)a.l[i] - b.l[i] - borrow;
+            d.l[i] = (uint32_t)t;
+            borrow = (t >> 63) & 1;
+        }
+        const fe tm = two_mod();
+        uint32_t mask = borrow ? 0xffffffffu : 0u;
+        fe r;
+        uint64_t c = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t t = (uint64_t)d.l[i] + (tm.l[i] & mask) + c;
+            r.l[i] = (uint32_t)t;
+            c = t >> 32;
+        }
+        return r;
+#else
+        return sub(a, b);
+#endif
+    }
+    static FF_HD fe ldbl(const fe& a) { return ladd(a, a); }
+    static FF_HD fe lneg(const fe& a) { return lsub(zero(), a); }  // 0 -> 0, otherwise 2 MOD - a
+    static FF_HD bool lis_zero(const fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t z = 0, m = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            z |= a.l[i];
+            m |= a.l[i] ^ Pm::MOD[i];
+        }
+        return z == 0 || m == 0;
+#else
+        return is_zero(a);
+#endif
+    }
+    // a*b - c*d in the lazy range: one reduction, < 2.52 MOD before, one conditional subtraction of MOD after
+    static FF_HD fe lmul_sub2(const fe& a, const fe& b, const fe& c, const fe& d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        fe x = mul_add2_nr(a, b, lneg(c), d);
+        const fe tm = two_mod();
+        // x >= 2 MOD ? x - MOD : x
+        fe t;
+        uint64_t borrow = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t u = (uint64_t)x.l[i] - tm.l[i] - borrow;
+            t.l[i] = (uint32_t)u;
+            borrow = (u >> 63) & 1;
+        }
+        uint32_t mask = borrow ? 0u : 0xffffffffu;  // no borrow: x >= 2 MOD
+        fe r;
+        uint64_t bb = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint64_t u = (uint64_t)x.l[i] - (Pm::MOD[i] & mask) - bb;
+            r.l[i] = (uint32_t)u;
+            bb = (u >> 63) & 1;
+        }
+        return r;
+#else
+        return mul_sub2(a, b, c, d);
 #endif
     }
 
