@@ -53,9 +53,9 @@ struct DevBuf {
 };
 
 struct MsmWorkspace {
-    DevBuf hist, off0, refs, offA, offB, partA, partB, bsum, chunk, grp, out, ptrs;
+    DevBuf hist, off0, refs, offA, offB, partA, partB, bsum, chunk, grp, out, ptrs, exc;
     void release() {
-        for (DevBuf* b : {&hist, &off0, &refs, &offA, &offB, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs})
+        for (DevBuf* b : {&hist, &off0, &refs, &offA, &offB, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs, &exc})
             b->release();
     }
 };

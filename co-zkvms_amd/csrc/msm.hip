@@ -20,6 +20,7 @@
 //     latency-bound bucket-reduction tail).
 // Results are returned as affine points, so the output is bit-exact to any correct MSM.
 #include "common.hpp"
+#include "fq9.cuh"
 
 static constexpr uint32_t NB = 1u << 15;  // buckets per group
 static constexpr int CH = 16;             // buckets per reduction chunk
@@ -374,24 +375,23 @@ static __device__ __forceinline__ uint32_t find_bucket(const uint32_t* off, uint
 }
 
 // ------------------------------------------------------------------ bucket accumulation
-// level 0: gather affine SRS/table points by reference -- THE dominant kernel of the whole path
-__global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
-                                                 const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                                                 uint32_t nb, uint32_t L, g1_xyzz* __restrict__ out) {
-    uint32_t t = blockIdx.x * TPB + threadIdx.x;
-    uint32_t total = off_out[nb];
-    if (t >= total) return;
+// level 0: gather affine SRS/table points by reference -- THE dominant kernel of the whole path.
+// Segment t of the balanced split: the bucket's cnt items go to its nseg = ceil(cnt / L) segments in equal shares
+// (ceil(cnt / nseg) each) instead of nseg-1 full segments and a short one, so the lanes of a wave run the same
+// number of iterations (the short remainders idled ~6 % of the lanes).
+static __device__ __forceinline__ void segment_range(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out, uint32_t nb,
+                                                     uint32_t t, uint32_t& begin, uint32_t& end) {
     uint32_t b = find_bucket(off_out, nb, t);
     uint32_t s = t - off_out[b];
-    // balanced split: the bucket's cnt items go to its nseg = ceil(cnt / L) segments in equal shares
-    // (ceil(cnt / nseg) each) instead of nseg-1 full segments and a short one, so the lanes of a wave run
-    // the same number of iterations (the short remainders idled ~6 % of the lanes)
     uint32_t cnt = off_in[b + 1] - off_in[b];
     uint32_t nseg = off_out[b + 1] - off_out[b];
     uint32_t per = (cnt + nseg - 1) / nseg;
-    (void)L;
-    uint32_t begin = off_in[b] + min(s * per, cnt);
-    uint32_t end = off_in[b] + min((s + 1) * per, cnt);
+    begin = off_in[b] + min(s * per, cnt);
+    end = off_in[b] + min((s + 1) * per, cnt);
+}
+// saturated-limb (8 x 32) gather: every special case handled (P == +-Q, infinity)
+static __device__ __forceinline__ g1_xyzz gather_segment(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs, uint32_t begin,
+                                                         uint32_t end) {
     g1_xyzz acc = G1::identity();
     // (measured: software-pipelining the gather costs 16 more VGPRs -> 3 waves/SIMD and gains nothing; with
     // 4 waves per SIMD the 64-byte HBM gathers already hide behind the ~3600-instruction mixed additions)
@@ -401,7 +401,58 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict_
         if (ref >> 31) p.y = Fq::neg(p.y);
         acc = G1::add_mixed(acc, p);
     }
-    xyzz_store(out + t, acc);
+    return acc;
+}
+__global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
+                                                 const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                                                 uint32_t nb, uint32_t L, g1_xyzz* __restrict__ out) {
+    uint32_t t = blockIdx.x * TPB + threadIdx.x;
+    uint32_t total = off_out[nb];
+    if (t >= total) return;
+    (void)L;
+    uint32_t begin, end;
+    segment_range(off_in, off_out, nb, t, begin, end);
+    xyzz_store(out + t, gather_segment(table, refs, begin, end));
+}
+// The same gather in 9 x 29-bit unsaturated limbs (fq9.cuh): no carry instructions in the products, no
+// conditional subtractions anywhere.  A segment that meets P == +-Q (repeated SRS points, cancelling digits) is
+// queued in `exc` ([0] = count, [1..] = segment ids) and redone by k_msm_accum0_fix with the saturated formulas.
+__global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
+                                                    const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                                                    uint32_t nb, g1_xyzz* __restrict__ out, uint32_t* __restrict__ exc) {
+    uint32_t t = blockIdx.x * TPB + threadIdx.x;
+    uint32_t total = off_out[nb];
+    if (t >= total) return;
+    uint32_t begin, end;
+    segment_range(off_in, off_out, nb, t, begin, end);
+    xyzz9 acc;
+    bool have = false;
+    for (uint32_t e = begin; e < end; e++) {
+        uint32_t ref = refs[e];
+        g1_affine p = affine_load(table + (ref & 0x7fffffffu));
+        if (G1::is_inf(p)) continue;
+        if (ref >> 31) p.y = Fq::neg(p.y);
+        f9 qx = f9_from_fe(p.x), qy = f9_from_fe(p.y);
+        if (!have) {
+            acc = xyzz9_from_affine(qx, qy);
+            have = true;
+        } else if (!madd9(acc, qx, qy)) {
+            exc[1 + atomicAdd(exc, 1u)] = t;
+            return;
+        }
+    }
+    xyzz_store(out + t, have ? xyzz9_to_xyzz(acc) : G1::identity());
+}
+__global__ void __launch_bounds__(TPB) k_msm_accum0_fix(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
+                                                     const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                                                     uint32_t nb, g1_xyzz* __restrict__ out, const uint32_t* __restrict__ exc) {
+    uint32_t n = exc[0];
+    for (uint32_t q = blockIdx.x * TPB + threadIdx.x; q < n; q += gridDim.x * TPB) {  // every lane reaches the end of the queue
+        uint32_t t = exc[1 + q];
+        uint32_t begin, end;
+        segment_range(off_in, off_out, nb, t, begin, end);
+        xyzz_store(out + t, gather_segment(table, refs, begin, end));
+    }
 }
 
 // level >= 1: fold partial sums
@@ -690,7 +741,15 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
+    if (pre) {
+        ws.exc.reserve((size_t)(maxseg0 + 2) * 4);
+        uint32_t* exc = ws.exc.as<uint32_t>();
+        HIP_TRY(hipMemsetAsync(exc, 0, 4, st));
+        k_msm_accum0_f9<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc);
+        k_msm_accum0_fix<<<256, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc);
+    } else {
+        k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
+    }
     if (ctx->prof_enabled) {
         HIP_TRY(hipEventRecord(e1, st));
         ctx->prof_events.push_back({e0, e1});
