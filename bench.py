@@ -16,7 +16,7 @@ all-gather over torch.distributed with a replicated coordinator on every rank; t
 `--shard segment`: N independent 2^20-cycle segments instead (no exchange at all).
 
 Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (MSM bucket accumulation,
-k_msm_accum0), timed live with HIP events on the stream it is launched on; `cpu_baseline` is the
+k_msm_accum0_f9), timed live with HIP events on the stream it is launched on; `cpu_baseline` is the
 oracle's plain-C restatement (OpenMP, all host cores) on a bounded sample of the same workload.
 """
 import argparse
@@ -133,7 +133,7 @@ def main():
     avg_ms = prof["total_ms"] / launches
     alg_per_launch = prof["alg_bytes"] / launches
     achieved_gbs = alg_per_launch / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
-    roofline = {"bound": "hbm", "kernel": "k_msm_accum0", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+    roofline = {"bound": "hbm", "kernel": "k_msm_accum0_f9", "achieved": round(achieved_gbs, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved_gbs / HBM_PEAK_GBS, 6), "traffic": None,
                 "launches": prof["launches"], "avg_launch_ms": round(avg_ms, 4), "algorithmic_bytes_per_launch": int(alg_per_launch),
                 "kernel_share_of_step": round(prof["total_ms"] / (dt * 1e3), 4)}
@@ -141,7 +141,7 @@ def main():
     # separate runs; profiles/r1_pmc_hbm.json).  bench.py cannot run rocprofv3 on itself, so this is the
     # per-launch average of the same command at the same sizes, reported only when sizes match the default.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_msm_accum0"]
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_msm_accum0_f9"]
         if log_n == 20:
             roofline["traffic"] = int((pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024)
             roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch, raw (uncalibrated for 64-B gathers); ~10x the algorithmic bytes "
@@ -151,15 +151,20 @@ def main():
     # the honest ceiling of this kernel is the integer ALU: measured Fq mont-mul peak
     ctx = pkg.Context(dev)
     lanes = 256 * 256 * 16
-    mm_ms = min(ctx.bench_montmul(lanes, 2000, 1) for _ in range(3))
+    # measured integer-ALU peak of the multiplier the gather kernel uses: variant 2 = 9 x 29-bit unsaturated limbs
+    # (162 mads per product; fq9.cuh); variant 1 = the saturated 8 x 32 multiplier, reported beside it
+    mm_ms = min(ctx.bench_montmul(lanes, 2000, 2) for _ in range(3))
     peak_gmul = lanes * 2000 / mm_ms / 1e6
+    sat_ms = min(ctx.bench_montmul(lanes, 2000, 1) for _ in range(3))
     ctx.close()
-    # one mixed XYZZ addition = 10 limb products (64 mads each) + 9 Montgomery reductions (72 mads each; Y3's two
-    # products share one) = 1288 mads = 9.47 stand-alone multiplications of 136 mads, which is what the peak counts
-    MULS_PER_MADD = 1288.0 / 136.0
+    # one mixed XYZZ addition in the gather kernel = 10 limb products + 9 Montgomery reductions of 81 mads each
+    # (Y3's two products share a reduction) = 1539 mads = 9.5 stand-alone products of 162 mads, which is what the
+    # peak counts
+    MULS_PER_MADD = 1539.0 / 162.0
     gmul = prof["point_adds"] * MULS_PER_MADD / (prof["total_ms"] * 1e-3) / 1e9 if prof["total_ms"] > 0 else 0.0
     roofline["int_alu"] = {"achieved": round(gmul, 2), "peak": round(peak_gmul, 2), "unit": "G Fq-montmul/s",
-                           "frac": round(gmul / peak_gmul, 4), "note": "mixed XYZZ addition = 10 products + 9 reductions = 9.47 multiplication equivalents; peak measured in this run"}
+                           "frac": round(gmul / peak_gmul, 4), "saturated_8x32_peak": round(lanes * 2000 / sat_ms / 1e6, 2),
+                           "note": "mixed XYZZ addition = 9.5 products of the 9x29-bit multiplier (10 limb products + 9 reductions); peak = that multiplier's dependent-product micro-benchmark, measured in this run"}
 
     out = {"metric": "RISC-V cycles proved/sec (co-Jolt hot path: PST13 commit + dense GKR grand product + openings)",
            "value": round(value, 1), "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
