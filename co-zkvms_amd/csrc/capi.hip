@@ -131,14 +131,23 @@ int cozk_ctx_create(int device, cozk_ctx** out) {
         delete ctx;
         return rc;
     }
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_live_ctx.insert(ctx);
+    }
     *out = ctx;
     return COZK_OK;
 }
 
 int cozk_ctx_destroy(cozk_ctx* ctx) {
     if (!ctx) return COZK_OK;
+    {
+        std::lock_guard<std::mutex> lk(g_ctx_mu);
+        g_live_ctx.erase(ctx);
+    }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    ctx->pool.destroy();
     for (auto& pr : ctx->prof_events) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
@@ -170,8 +179,7 @@ int cozk_vec_alloc(cozk_ctx* ctx, size_t n, int kind, cozk_vec** out) {
     return cozk_guard(ctx, [&] {
         COZK_REQUIRE(ctx && out && scalar_kind_bytes(kind), "vec_alloc: bad argument");
         size_t bytes = n * scalar_kind_bytes(kind);
-        void* d = nullptr;
-        HIP_TRY(hipMalloc(&d, bytes ? bytes : 16));
+        void* d = ctx_dev_alloc(ctx, bytes);
         *out = new cozk_vec{ctx, n, kind, d, bytes, true};
     });
 }
@@ -200,7 +208,7 @@ int cozk_vec_download(cozk_ctx* ctx, const cozk_vec* v, void* host) {
 
 int cozk_vec_free(cozk_vec* v) {
     if (!v) return COZK_OK;
-    if (v->owned && v->d) (void)hipFree(v->d);
+    if (v->owned && v->d) ctx_dev_free(v->ctx, v->d);
     delete v;
     return COZK_OK;
 }

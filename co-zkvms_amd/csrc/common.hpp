@@ -4,6 +4,9 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <string>
+#include <mutex>
+#include <unordered_map>
+#include <unordered_set>
 #include <vector>
 #include <stdexcept>
 
@@ -60,9 +63,66 @@ struct MsmWorkspace {
     }
 };
 
+// Caching device allocator, one per context.  hipFree synchronises the whole device (~130 us measured) and the
+// round loops create and drop hundreds of short-lived buffers per proof (eq tables, bound layers, fold outputs):
+// freed blocks are parked per size class and handed out again.  Reuse is stream-ordered by construction: every
+// user of a block enqueues on the context's one stream, so work on the old contents precedes work on the new.
+struct DevPool {
+    std::unordered_map<size_t, std::vector<void*>> parked;
+    std::unordered_map<void*, size_t> live;  // block -> size class
+    size_t parked_bytes = 0;
+    static size_t size_class(size_t bytes) {  // four classes per octave: <= 25 % slack
+        if (bytes <= 256) return 256;
+        size_t top = (size_t)1 << (63 - __builtin_clzll((unsigned long long)bytes));
+        size_t q = top >> 2;
+        return (bytes + q - 1) / q * q;
+    }
+    void trim() {
+        for (auto& kv : parked)
+            for (void* p : kv.second) (void)hipFree(p);
+        parked.clear();
+        parked_bytes = 0;
+    }
+    void* alloc(size_t bytes) {
+        size_t c = size_class(bytes);
+        auto it = parked.find(c);
+        if (it != parked.end() && !it->second.empty()) {
+            void* p = it->second.back();
+            it->second.pop_back();
+            parked_bytes -= c;
+            live[p] = c;
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, c);
+        if (e != hipSuccess) {  // give the parked blocks back and try once more
+            (void)hipGetLastError();
+            trim();
+            HIP_TRY(hipMalloc(&p, c));
+        }
+        live[p] = c;
+        return p;
+    }
+    // false: not one of ours
+    bool release(void* p) {
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        parked[it->second].push_back(p);
+        parked_bytes += it->second;
+        live.erase(it);
+        return true;
+    }
+    void destroy() {
+        trim();
+        for (auto& kv : live) (void)hipFree(kv.first);
+        live.clear();
+    }
+};
+
 struct cozk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    DevPool pool;
     std::string last_error;
     MsmWorkspace msm_ws;
     DevBuf scratch;       // small reductions (round evaluations, block partials)
@@ -109,8 +169,36 @@ static inline size_t scalar_kind_bytes(int kind) {
     }
 }
 
+// registry of live contexts (an object may outlive its context in a host language with a GC: its free then falls
+// back to hipFree) and the context of the ABI call running on this thread (for allocations made deep inside it)
+inline std::mutex g_ctx_mu;
+inline std::unordered_set<cozk_ctx*> g_live_ctx;
+inline thread_local cozk_ctx* t_cur_ctx = nullptr;
+static inline bool ctx_is_live(cozk_ctx* ctx) {
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    return g_live_ctx.count(ctx) != 0;
+}
+static inline void* ctx_dev_alloc(cozk_ctx* ctx, size_t bytes) {
+    if (!ctx) {
+        void* p = nullptr;
+        HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
+        return p;
+    }
+    return ctx->pool.alloc(bytes ? bytes : 16);
+}
+static inline void ctx_dev_free(cozk_ctx* ctx, void* p) {
+    if (!p) return;
+    if (ctx && ctx_is_live(ctx) && ctx->pool.release(p)) return;
+    (void)hipFree(p);
+}
+
 template <class F>
 static int cozk_guard(cozk_ctx* ctx, F&& f) {
+    struct Cur {
+        cozk_ctx* prev;
+        explicit Cur(cozk_ctx* c) : prev(t_cur_ctx) { t_cur_ctx = c; }
+        ~Cur() { t_cur_ctx = prev; }
+    } cur(ctx);
     try {
         if (ctx) HIP_TRY(hipSetDevice(ctx->device));
         f();

@@ -515,11 +515,8 @@ __global__ void __launch_bounds__(1024) k_eq_build(const fe* __restrict__ r, int
 }
 
 // ------------------------------------------------------------------ host helpers
-static fe* dev_alloc_fe(size_t n) {
-    void* p = nullptr;
-    HIP_TRY(hipMalloc(&p, (n ? n : 1) * sizeof(fe)));
-    return (fe*)p;
-}
+// from the pool of the context whose ABI call is running on this thread (cozk_guard)
+static fe* dev_alloc_fe(size_t n) { return (fe*)ctx_dev_alloc(t_cur_ctx, (n ? n : 1) * sizeof(fe)); }
 
 // copy k small results from device scratch to host (sync)
 static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
@@ -608,12 +605,12 @@ int cozk_poly_chunk(cozk_ctx* ctx, const cozk_poly* src, size_t offset, size_t l
 int cozk_poly_free(cozk_poly* p) {
     if (!p) return COZK_OK;
     if (p->own0) {
-        if (p->a0) (void)hipFree(p->a0);
-        if (p->b0) (void)hipFree(p->b0);
+        if (p->a0) ctx_dev_free(p->ctx, p->a0);
+        if (p->b0) ctx_dev_free(p->ctx, p->b0);
     }
     for (int w = 0; w < 2; w++)
         for (int c = 0; c < 2; c++)
-            if (p->buf[w][c]) (void)hipFree(p->buf[w][c]);
+            if (p->buf[w][c]) ctx_dev_free(p->ctx, p->buf[w][c]);
     delete p;
     return COZK_OK;
 }
@@ -657,7 +654,7 @@ int cozk_poly_bind(cozk_ctx* ctx, cozk_poly* p, const uint64_t r[4], int order) 
             dst = p->cur < 0 ? 0 : 1 - p->cur;
             if (p->cap[dst] < n) {
                 for (int c = 0; c < 2; c++) {
-                    if (p->buf[dst][c]) HIP_TRY(hipFree(p->buf[dst][c]));
+                    if (p->buf[dst][c]) ctx_dev_free(p->ctx, p->buf[dst][c]);
                     p->buf[dst][c] = nullptr;
                 }
                 p->buf[dst][0] = dev_alloc_fe(n);
@@ -1082,7 +1079,7 @@ int cozk_layer_free(cozk_layer* l) {
     if (!l) return COZK_OK;
     for (int w = 0; w < 2; w++)
         for (int c = 0; c < 2; c++)
-            if (l->buf[w][c]) (void)hipFree(l->buf[w][c]);
+            if (l->buf[w][c]) ctx_dev_free(l->ctx, l->buf[w][c]);
     delete l;
     return COZK_OK;
 }
@@ -1141,7 +1138,7 @@ int cozk_layer_bind(cozk_ctx* ctx, cozk_layer* l, const uint64_t r[4]) {
         int dst = 1 - l->cur;
         if (l->cap[dst] < nout) {
             for (int c = 0; c < 2; c++) {
-                if (l->buf[dst][c]) HIP_TRY(hipFree(l->buf[dst][c]));
+                if (l->buf[dst][c]) ctx_dev_free(l->ctx, l->buf[dst][c]);
                 l->buf[dst][c] = nullptr;
             }
             l->buf[dst][0] = dev_alloc_fe(nout);
@@ -1185,8 +1182,8 @@ int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** ou
 int cozk_spliteq_free(cozk_spliteq* e) {
     if (!e) return COZK_OK;
     for (int k = 0; k < 2; k++) {
-        if (e->E1[k]) (void)hipFree(e->E1[k]);
-        if (e->E2[k]) (void)hipFree(e->E2[k]);
+        if (e->E1[k]) ctx_dev_free(e->ctx, e->E1[k]);
+        if (e->E2[k]) ctx_dev_free(e->ctx, e->E2[k]);
     }
     delete e;
     return COZK_OK;
