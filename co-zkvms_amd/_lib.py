@@ -103,6 +103,8 @@ SIGNATURES = {
     "cozk_layer_clone": (_i, [_vp, _vp, _pp]),
     "cozk_layer_bind": (_i, [_vp, _vp, _vp]),
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cozk_layer_prove_rounds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cozk_layer_final_claims": (_i, [_vp, _vp, _vp]),
     "cozk_layer_output_local": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _pp]),
     "cozk_rep3_mul_vec_local": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _u64, _u64, _u64, _pp]),

@@ -157,6 +157,8 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
     ctx->scratch2.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->msm_pinned) (void)hipHostFree(ctx->msm_pinned);
+    if (ctx->round_flag) (void)hipHostFree(ctx->round_flag);
+    if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->msm_event) (void)hipEventDestroy(ctx->msm_event);
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string>
 #include <mutex>
 #include <unordered_map>
@@ -129,6 +130,9 @@ struct cozk_ctx {
     DevBuf scratch2;
     void* pinned = nullptr;  // pinned host staging for small D2H results
     size_t pinned_cap = 0;
+    void* mailbox = nullptr;         // fine-grained pinned host memory shared with the resident round kernel
+    uint32_t* round_flag = nullptr;  // pinned word a stream write bumps behind each round's finishing kernel
+    uint32_t round_seq = 0;
     uint32_t* msm_pinned = nullptr;  // largest bucket of the current MSM launch set (read back behind an event)
     hipEvent_t msm_event = nullptr;
     // timing of the dominant kernel (bench roofline): accumulated HIP-event time of the
@@ -179,7 +183,8 @@ static inline bool ctx_is_live(cozk_ctx* ctx) {
     return g_live_ctx.count(ctx) != 0;
 }
 static inline void* ctx_dev_alloc(cozk_ctx* ctx, size_t bytes) {
-    if (!ctx) {
+    static const bool no_pool = getenv("COZK_NO_POOL") != nullptr;  // diagnostic: plain hipMalloc / hipFree
+    if (!ctx || no_pool) {
         void* p = nullptr;
         HIP_TRY(hipMalloc(&p, bytes ? bytes : 16));
         return p;

@@ -276,9 +276,13 @@ static void worker_main(cozk_harness* h, PartyState& ps, StarNetWorker* star, Ri
     HIP_TRY(hipStreamSynchronize(ps.ctx->stream));
     double t2 = now_ms();
     ps.t_construct = t2 - t1;
+    t_round_trace = RoundTrace();
     std::vector<fe> r_gp = gp.prove_grand_product_worker(env);
     double t3 = now_ms();
     ps.t_gp = t3 - t2;
+    if (getenv("COZK_TRACE_ROUNDS"))
+        fprintf(stderr, "[rounds] party %d: %llu rounds, round loop %.2f ms (of which star round trips %.2f ms), gp_prove %.2f ms\n", ps.party,
+                (unsigned long long)t_round_trace.rounds, t_round_trace.t_round / 1e3, t_round_trace.t_star / 1e3, ps.t_gp);
     // harness check message (not part of the proof): additive share of leaves(r_gp)
     {
         // the original leaves as a dense polynomial over (circuit, position, l/r) variables

@@ -12,6 +12,7 @@
 // `mode` = COZK_MODE_REP3 (three parties, shares {a,b}) or COZK_MODE_PLAIN (one party, the plain
 // prover: same message schedule with a single worker whose additive share is the value itself).
 #pragma once
+#include <chrono>
 #include <memory>
 
 #include "net.hpp"
@@ -121,14 +122,28 @@ struct SumcheckResult {
     Share left, right;
 };
 
-// Rep3BatchedCubicSumcheckWorker::prove_sumcheck (sumcheck.rs:96-131)
-static SumcheckResult prove_sumcheck(WorkerEnv& env, cozk_layer* layer, const fe& claim, cozk_spliteq* eq, int num_rounds) {
-    SumcheckResult res;
-    fe previous_claim = claim;
-    for (int round = 0; round < num_rounds; round++) {
-        uint64_t pc[4], coeffs[16];
-        fe_to_u64x4(previous_claim, pc);
-        rc_check(cozk_layer_compute_cubic(env.ctx, layer, eq, pc, coeffs), env.ctx, "compute_cubic");
+// optional phase accounting of the round loop (COZK_TRACE_ROUNDS=1): kernel + drain vs star round trip
+struct RoundTrace {
+    double t_round = 0, t_star = 0, t_rest = 0;
+    uint64_t rounds = 0;
+};
+inline thread_local RoundTrace t_round_trace;
+static inline double trace_now_us() {
+    return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Rep3BatchedCubicSumcheckWorker::prove_sumcheck (sumcheck.rs:96-131).  The round loop itself lives behind the
+// ABI (cozk_layer_prove_rounds: per-round launches while the layer is large, one resident kernel for its tail);
+// the star exchange of each round is the callback.
+struct RoundCtx {
+    WorkerEnv* env;
+    std::string error;
+};
+static int prove_sumcheck_round_cb(void* user, int /*round*/, const uint64_t coeffs[16], uint64_t r_out[4], uint64_t next_claim_out[4]) {
+    RoundCtx* rc = static_cast<RoundCtx*>(user);
+    try {
+        WorkerEnv& env = *rc->env;
+        double tb = trace_now_us();
         Writer w;
         std::vector<fe> cf(4);
         for (int i = 0; i < 4; i++) cf[i] = fe_from_u64x4(coeffs + 4 * i);
@@ -138,15 +153,28 @@ static SumcheckResult prove_sumcheck(WorkerEnv& env, cozk_layer* layer, const fe
         Reader rd(req);
         fe r_j = rd.fr();
         fe next_claim = rd.fr();
-        res.r.push_back(r_j);
-        uint64_t rr[4];
-        fe_to_u64x4(r_j, rr);
-        rc_check(cozk_layer_bind(env.ctx, layer, rr), env.ctx, "layer_bind");
-        rc_check(cozk_spliteq_bind(env.ctx, eq, rr), env.ctx, "spliteq_bind");
-        previous_claim = env.additive_trivial(next_claim);
+        fe_to_u64x4(r_j, r_out);
+        fe_to_u64x4(env.additive_trivial(next_claim), next_claim_out);
+        t_round_trace.t_star += trace_now_us() - tb;
+        t_round_trace.rounds++;
+        return 0;
+    } catch (const std::exception& e) {
+        rc->error = e.what();
+        return 1;
     }
-    uint64_t fc[16];
-    rc_check(cozk_layer_final_claims(env.ctx, layer, fc), env.ctx, "final_claims");
+}
+static SumcheckResult prove_sumcheck(WorkerEnv& env, cozk_layer* layer, const fe& claim, cozk_spliteq* eq, int num_rounds) {
+    SumcheckResult res;
+    uint64_t pc[4], fc[16];
+    fe_to_u64x4(claim, pc);
+    std::vector<uint64_t> rs((size_t)4 * (num_rounds > 0 ? num_rounds : 1));
+    RoundCtx rc{&env, {}};
+    double ta = trace_now_us();
+    int st = cozk_layer_prove_rounds(env.ctx, layer, eq, pc, num_rounds, prove_sumcheck_round_cb, &rc, rs.data(), fc);
+    t_round_trace.t_round += trace_now_us() - ta;
+    if (st != COZK_OK && !rc.error.empty()) throw CozkError(COZK_ERR_INTERNAL, rc.error);
+    rc_check(st, env.ctx, "layer_prove_rounds");
+    for (int j = 0; j < num_rounds; j++) res.r.push_back(fe_from_u64x4(rs.data() + 4 * j));
     res.left = Share{fe_from_u64x4(fc), fe_from_u64x4(fc + 4)};
     res.right = Share{fe_from_u64x4(fc + 8), fe_from_u64x4(fc + 12)};
     Writer w;

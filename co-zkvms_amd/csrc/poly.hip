@@ -7,6 +7,9 @@
 // All kernels are streaming kernels on 32-byte Montgomery elements (16-byte vector loads per lane);
 // round results (3-4 field elements) are reduced in-kernel (wave shuffle tree + LDS), finished by a
 // one-block kernel, and returned through pinned host memory.
+#include <atomic>
+#include <chrono>
+#include <string.h>
 #include "poly.cuh"
 
 static constexpr int PT = 256;      // threads per block
@@ -234,6 +237,271 @@ __global__ void __launch_bounds__(PT) k_layer_cubic(const fe* __restrict__ a, co
     if (threadIdx.x == 0) fe_store(partial + gridDim.x + blockIdx.x, s2);
     s3 = fr_block_sum(s3, sh4);
     if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, s3);
+}
+
+// One whole sumcheck round of a SMALL layer in a single one-workgroup launch: bind the layer and the split-eq
+// tables with the previous challenge (k_layer_bind + SplitEqPolynomial::bind), then the cubic sums of the new
+// round (k_layer_cubic) and their block reduction straight into the pinned result slot.  The GKR proof is ~270
+// rounds deep and ~200 of them touch <= 8192 elements: as five separate launches each costs more in launch
+// gaps than in work.
+static constexpr int RT = 1024;
+static constexpr size_t ROUND_SMALL_MAX = 2048;  // layer length before the bind (measured: a single workgroup loses above 2^11)
+template <int NC>
+__global__ void __launch_bounds__(RT) k_layer_round_small(const fe* __restrict__ ia, const fe* __restrict__ ib, fe* oa, fe* ob, size_t len_in,
+                                                       int do_bind, fe r, const fe* fold_in, fe* fold_out, size_t fold_n, fe* scale_vec,
+                                                       size_t scale_n, const fe* ca, const fe* cb, size_t len, const fe* E1, size_t E1_half,
+                                                       const fe* E2, size_t E2_len, int nested, fe* __restrict__ res) {
+    __shared__ fe sh16[16];
+    if (do_bind) {
+        size_t nch_in = (len_in + 3) / 4;
+        for (size_t c = threadIdx.x; c < nch_in; c += RT) {
+            Sh<NC> u0 = sh_load_or_zero<NC>(ia, ib, 4 * c, len_in), u1 = sh_load_or_zero<NC>(ia, ib, 4 * c + 1, len_in);
+            Sh<NC> u2 = sh_load_or_zero<NC>(ia, ib, 4 * c + 2, len_in), u3 = sh_load_or_zero<NC>(ia, ib, 4 * c + 3, len_in);
+            sh_store<NC>(oa, ob, 2 * c, sh_lerp<NC>(u0, u2, r));
+            sh_store<NC>(oa, ob, 2 * c + 1, sh_lerp<NC>(u1, u3, r));
+        }
+        for (size_t i = threadIdx.x; i < fold_n; i += RT) {
+            fe lo = fe_load(fold_in + 2 * i), hi = fe_load(fold_in + 2 * i + 1);
+            fe_store(fold_out + i, Fr::add(lo, Fr::mul(Fr::sub(hi, lo), r)));
+        }
+        __syncthreads();
+        if (scale_n) {  // E1 just collapsed to one value: it multiplies E2 from now on
+            fe s = fe_load(fold_out);
+            for (size_t i = threadIdx.x; i < scale_n; i += RT) fe_store(scale_vec + i, Fr::mul(fe_load(scale_vec + i), s));
+            __syncthreads();
+        }
+    }
+    size_t nch = (len + 3) / 4;
+    size_t limit = nested ? E1_half * E2_len : E2_len / 2;
+    if (nch > limit) nch = limit;
+    fe s0 = Fr::zero(), s2 = Fr::zero(), s3 = Fr::zero();
+    for (size_t c = threadIdx.x; c < nch; c += RT) {
+        fe e[3];
+        fe scale = Fr::zero();
+        if (nested) {
+            size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+            eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
+            scale = fe_load(E2 + x2);
+        } else {
+            eq3(fe_load(E2 + 2 * c), fe_load(E2 + 2 * c + 1), e);
+        }
+        Sh<NC> l0 = sh_load_or_zero<NC>(ca, cb, 4 * c, len), r0 = sh_load_or_zero<NC>(ca, cb, 4 * c + 1, len);
+        Sh<NC> l1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 2, len), r1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 3, len);
+        Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
+        Sh<NC> l2 = sh_add<NC>(l1, ml), r2 = sh_add<NC>(r1, mr);
+        Sh<NC> l3 = sh_add<NC>(l2, ml), r3 = sh_add<NC>(r2, mr);
+        fe t0 = Fr::mul(sh_local_mul<NC>(l0, r0), e[0]);
+        fe t2 = Fr::mul(sh_local_mul<NC>(l2, r2), e[1]);
+        fe t3 = Fr::mul(sh_local_mul<NC>(l3, r3), e[2]);
+        if (nested) {
+            t0 = Fr::mul(t0, scale);
+            t2 = Fr::mul(t2, scale);
+            t3 = Fr::mul(t3, scale);
+        }
+        s0 = Fr::add(s0, t0);
+        s2 = Fr::add(s2, t2);
+        s3 = Fr::add(s3, t3);
+    }
+    s0 = fr_block_sum(s0, sh16);
+    if (threadIdx.x == 0) fe_store(res, s0);
+    s2 = fr_block_sum(s2, sh16);
+    if (threadIdx.x == 0) fe_store(res + 1, s2);
+    s3 = fr_block_sum(s3, sh16);
+    if (threadIdx.x == 0) fe_store(res + 2, s3);
+}
+
+// ------------------------------------------------------------------ persistent round kernel (host mailbox)
+// A launch-and-drain costs ~38 us on this platform however small the kernel (measured per round, 2^3 .. 2^19
+// elements alike), and a grand product has ~170 rounds on layers of <= 2048 elements.  For those tails ONE
+// single-workgroup kernel stays resident for all remaining rounds of the layer's sumcheck and talks to the host
+// through a mailbox in fine-grained pinned memory: it publishes the three cubic sums of a round, spins (lane 0
+// only; the other waves sit at the barrier) until the host has posted the challenge, binds layer + eq tables,
+// and goes on -- a PCIe round trip (~3 us) per round instead of a launch.  After the last challenge it binds once
+// more and publishes the final claims.  Every wait is bounded by the wall clock (MB_TIMEOUT_TICKS of the 100 MHz
+// counter): a host that never answers makes the kernel raise `status` and return, so the grid always drains.
+struct alignas(64) RoundMailbox {
+    uint32_t cmd_seq;  // host -> device: challenge number k has been posted (k = 1, 2, ...)
+    uint32_t abort;    // host -> device: give up
+    uint32_t pad0[14];
+    fe r;              // host -> device: the challenge
+    uint32_t pad1[8];
+    uint32_t res_seq;  // device -> host: result number k is ready
+    uint32_t status;   // device -> host: 0 ok, 1 timed out waiting for the host, 2 aborted
+    uint32_t pad2[14];
+    fe res[4];         // device -> host: cubic sums g(0), g(2), g(3); final: left.a, left.b, right.a, right.b
+    unsigned long long dbg[8];  // device -> host: 100 MHz ticks spent waiting / binding / in the cubic sums / publishing
+};
+static constexpr long long MB_TIMEOUT_TICKS = 10ll * 100000000ll;  // 10 s
+static constexpr size_t ROUND_PERSIST_MAX = 2048;
+
+template <int NC>
+__global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0, fe* la1, fe* lb1, int lcur, size_t len, fe* e1_0, fe* e1_1,
+                                                             int c1, size_t E1_len, fe* e2_0, fe* e2_1, int c2, size_t E2_len, int nrounds,
+                                                             int bind_first, fe r_first, RoundMailbox* mb) {
+    __shared__ fe sh16[16];
+    __shared__ fe sh_r;
+    __shared__ int sh_ok;
+    fe* la[2] = {la0, la1};
+    fe* lb[2] = {lb0, lb1};
+    fe* e1[2] = {e1_0, e1_1};
+    fe* e2[2] = {e2_0, e2_1};
+    uint32_t seq = 0;
+    long long tk0 = wall_clock64(), tk_wait = 0, tk_bind = 0, tk_cubic = 0, tk_pub = 0;
+    // rounds 0 .. nrounds-1 publish cubic sums; "round" nrounds only binds and publishes the final claims
+    for (int round = 0; round <= nrounds; round++) {
+        bool do_bind = round > 0 || bind_first;
+        fe r = r_first;
+        tk0 = wall_clock64();
+        if (round > 0) {
+            if (threadIdx.x == 0) {
+                long long t0 = wall_clock64();
+                int ok = 1;
+                for (;;) {
+                    if (__hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint32_t)round) break;
+                    if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                        ok = 0;
+                        __hip_atomic_store(&mb->status, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    if (wall_clock64() - t0 > MB_TIMEOUT_TICKS) {
+                        ok = 0;
+                        __hip_atomic_store(&mb->status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (ok) sh_r = fe_load(&mb->r);  // two 16-byte loads behind the acquire: one PCIe round trip, not eight
+                sh_ok = ok;
+            }
+            __syncthreads();
+            if (!sh_ok) return;  // uniform: every wave reads the same shared word after the barrier
+            r = sh_r;
+        }
+        {
+            long long t = wall_clock64();
+            tk_wait += t - tk0;
+            tk0 = t;
+        }
+        if (do_bind) {
+            const fe *ia = la[lcur], *ib = lb[lcur];
+            fe *oa = la[1 - lcur], *ob = lb[1 - lcur];
+            size_t nch_in = (len + 3) / 4;
+            for (size_t c = threadIdx.x; c < nch_in; c += RT) {
+                Sh<NC> u0 = sh_load_or_zero<NC>(ia, ib, 4 * c, len), u1 = sh_load_or_zero<NC>(ia, ib, 4 * c + 1, len);
+                Sh<NC> u2 = sh_load_or_zero<NC>(ia, ib, 4 * c + 2, len), u3 = sh_load_or_zero<NC>(ia, ib, 4 * c + 3, len);
+                sh_store<NC>(oa, ob, 2 * c, sh_lerp<NC>(u0, u2, r));
+                sh_store<NC>(oa, ob, 2 * c + 1, sh_lerp<NC>(u1, u3, r));
+            }
+            lcur = 1 - lcur;
+            len = 2 * nch_in;
+            // SplitEqPolynomial::bind
+            if (E1_len == 1) {
+                size_t n = E2_len / 2;
+                const fe* in = e2[c2];
+                fe* out = e2[1 - c2];
+                for (size_t i = threadIdx.x; i < n; i += RT) {
+                    fe lo = fe_load(in + 2 * i), hi = fe_load(in + 2 * i + 1);
+                    fe_store(out + i, Fr::add(lo, Fr::mul(Fr::sub(hi, lo), r)));
+                }
+                c2 = 1 - c2;
+                E2_len = n;
+                __syncthreads();
+            } else {
+                size_t n = E1_len / 2;
+                const fe* in = e1[c1];
+                fe* out = e1[1 - c1];
+                for (size_t i = threadIdx.x; i < n; i += RT) {
+                    fe lo = fe_load(in + 2 * i), hi = fe_load(in + 2 * i + 1);
+                    fe_store(out + i, Fr::add(lo, Fr::mul(Fr::sub(hi, lo), r)));
+                }
+                c1 = 1 - c1;
+                E1_len = n;
+                __syncthreads();
+                if (n == 1) {
+                    fe sc = fe_load(e1[c1]);
+                    fe* v = e2[c2];
+                    for (size_t i = threadIdx.x; i < E2_len; i += RT) fe_store(v + i, Fr::mul(fe_load(v + i), sc));
+                    __syncthreads();
+                }
+            }
+        }
+        seq++;
+        {
+            long long t = wall_clock64();
+            tk_bind += t - tk0;
+            tk0 = t;
+        }
+        if (round == nrounds) {  // final claims: coeffs[0], coeffs[1] of the fully bound layer
+            if (threadIdx.x == 0) {
+                mb->dbg[0] = (unsigned long long)tk_wait;
+                mb->dbg[1] = (unsigned long long)tk_bind;
+                mb->dbg[2] = (unsigned long long)tk_cubic;
+                mb->dbg[3] = (unsigned long long)tk_pub;
+                fe z = Fr::zero();
+                fe v[4] = {fe_load(la[lcur]), NC == 2 ? fe_load(lb[lcur]) : z, fe_load(la[lcur] + 1), NC == 2 ? fe_load(lb[lcur] + 1) : z};
+                for (int k = 0; k < 4; k++) fe_store(&mb->res[k], v[k]);
+                __threadfence_system();
+                __hip_atomic_store(&mb->res_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            return;
+        }
+        // cubic sums of this round
+        const fe *ca = la[lcur], *cb = lb[lcur];
+        const fe *E1 = e1[c1], *E2 = e2[c2];
+        const bool nested = E1_len != 1;
+        const size_t E1_half = E1_len / 2;
+        size_t nch = (len + 3) / 4;
+        size_t limit = nested ? E1_half * E2_len : E2_len / 2;
+        if (nch > limit) nch = limit;
+        fe s0 = Fr::zero(), s2 = Fr::zero(), s3 = Fr::zero();
+        for (size_t c = threadIdx.x; c < nch; c += RT) {
+            fe e[3];
+            fe scale = Fr::zero();
+            if (nested) {
+                size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+                eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
+                scale = fe_load(E2 + x2);
+            } else {
+                eq3(fe_load(E2 + 2 * c), fe_load(E2 + 2 * c + 1), e);
+            }
+            Sh<NC> l0 = sh_load_or_zero<NC>(ca, cb, 4 * c, len), r0 = sh_load_or_zero<NC>(ca, cb, 4 * c + 1, len);
+            Sh<NC> l1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 2, len), r1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 3, len);
+            Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
+            Sh<NC> l2 = sh_add<NC>(l1, ml), r2 = sh_add<NC>(r1, mr);
+            Sh<NC> l3 = sh_add<NC>(l2, ml), r3 = sh_add<NC>(r2, mr);
+            fe t0 = Fr::mul(sh_local_mul<NC>(l0, r0), e[0]);
+            fe t2 = Fr::mul(sh_local_mul<NC>(l2, r2), e[1]);
+            fe t3 = Fr::mul(sh_local_mul<NC>(l3, r3), e[2]);
+            if (nested) {
+                t0 = Fr::mul(t0, scale);
+                t2 = Fr::mul(t2, scale);
+                t3 = Fr::mul(t3, scale);
+            }
+            s0 = Fr::add(s0, t0);
+            s2 = Fr::add(s2, t2);
+            s3 = Fr::add(s3, t3);
+        }
+        s0 = fr_block_sum(s0, sh16);
+        s2 = fr_block_sum(s2, sh16);
+        s3 = fr_block_sum(s3, sh16);
+        {
+            long long t = wall_clock64();
+            tk_cubic += t - tk0;
+            tk0 = t;
+        }
+        if (threadIdx.x == 0) {
+            fe v[3] = {s0, s2, s3};
+            for (int k = 0; k < 3; k++) fe_store(&mb->res[k], v[k]);
+            __threadfence_system();
+            __hip_atomic_store(&mb->res_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        __syncthreads();
+        {
+            long long t = wall_clock64();
+            tk_pub += t - tk0;
+            tk0 = t;
+        }
+    }
 }
 
 static __device__ __forceinline__ uint64_t sm_next(uint64_t& s) {
@@ -521,10 +789,32 @@ static fe* dev_alloc_fe(size_t n) { return (fe*)ctx_dev_alloc(t_cur_ctx, (n ? n 
 // copy k small results from device scratch to host (sync)
 static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
     fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
-    // round results are written by the finishing kernel straight into pinned (device-visible) host memory:
-    // then there is nothing to copy, only the stream to drain
-    if (d != pin) HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (d != pin) {
+        HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    } else {
+        // Round results are written by the finishing kernel straight into pinned (device-visible) host memory, so
+        // there is nothing to copy -- only the stream to drain, ~270 times per grand product.  A stream memory
+        // write of a sequence number behind the kernel + a host spin on that word replaces hipStreamSynchronize's
+        // event/interrupt path (tens of microseconds) with a cache-line hand-off.
+        static const bool use_flag = getenv("COZK_SYNC_ROUNDS") == nullptr;
+        if (use_flag) {
+            if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocDefault));
+            uint32_t seq = ++ctx->round_seq;
+            HIP_TRY(hipStreamWriteValue32(ctx->stream, (void*)ctx->round_flag, seq, 0));
+            volatile uint32_t* f = ctx->round_flag;
+            uint64_t spins = 0;
+            while (*f != seq) {
+                __builtin_ia32_pause();
+                if (++spins > (1ull << 22)) {  // ~10 ms without news: fall back to the blocking wait (also surfaces errors)
+                    HIP_TRY(hipStreamSynchronize(ctx->stream));
+                    break;
+                }
+            }
+        } else {
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+        }
+    }
     for (size_t i = 0; i < k; i++) h[i] = pin[i];
 }
 // where a finishing kernel should put k round results (pinned host memory, mapped into the device)
@@ -1254,6 +1544,207 @@ int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
         fe cf[4];
         unipoly_from_evals(ev, 4, cf);
         for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], out_coeffs + 4 * i);
+    });
+}
+
+// One round of prove_sumcheck (co-jolt/src/subprotocols/sumcheck.rs:107-122) per call: bind the layer and the
+// split-eq polynomial with the previous round's challenge `r` (NULL in the first round), then compute_cubic.
+// Layers of <= ROUND_SMALL_MAX elements take the single-launch kernel; larger ones the separate kernels.
+int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64_t* r, const uint64_t prev_claim[4],
+                     uint64_t out_coeffs[16]) {
+    if (!ctx || !l || !e || !prev_claim || !out_coeffs) return COZK_ERR_INVALID_ARG;
+    static const size_t small_max = getenv("COZK_ROUND_SMALL") ? (size_t)atol(getenv("COZK_ROUND_SMALL")) : ROUND_SMALL_MAX;
+    if (l->len > small_max) {
+        if (r) {
+            int rc = cozk_layer_bind(ctx, l, r);
+            if (rc != COZK_OK) return rc;
+            rc = cozk_spliteq_bind(ctx, e, r);
+            if (rc != COZK_OK) return rc;
+        }
+        return cozk_layer_compute_cubic(ctx, l, e, prev_claim, out_coeffs);
+    }
+    return cozk_guard(ctx, [&] {
+        const fe *ia = l->buf[l->cur][0], *ib = l->buf[l->cur][1];
+        fe *oa = nullptr, *ob = nullptr;
+        size_t len_in = l->len;
+        const fe* fold_in = nullptr;
+        fe* fold_out = nullptr;
+        size_t fold_n = 0, scale_n = 0;
+        fe* scale_vec = nullptr;
+        fe rr = Fr::zero();
+        if (r) {
+            COZK_REQUIRE(l->len >= 2, "layer_round: layer already fully bound");
+            rr = fe_from_u64x4(r);
+            size_t nout = 2 * ((l->len + 3) / 4);
+            int dst = 1 - l->cur;
+            if (l->cap[dst] < nout) {
+                for (int c = 0; c < 2; c++) {
+                    if (l->buf[dst][c]) ctx_dev_free(l->ctx, l->buf[dst][c]);
+                    l->buf[dst][c] = nullptr;
+                }
+                l->buf[dst][0] = dev_alloc_fe(nout);
+                if (l->mode == COZK_MODE_REP3) l->buf[dst][1] = dev_alloc_fe(nout);
+                l->cap[dst] = nout;
+            }
+            oa = l->buf[dst][0];
+            ob = l->buf[dst][1];
+            l->cur = dst;
+            l->len = nout;
+            // SplitEqPolynomial::bind bookkeeping (cozk_spliteq_bind)
+            if (e->E1_len == 1) {
+                COZK_REQUIRE(e->E2_len >= 2, "layer_round: eq polynomial already fully bound");
+                fold_n = e->E2_len / 2;
+                fold_in = e->E2[e->c2];
+                fold_out = e->E2[1 - e->c2];
+                e->c2 = 1 - e->c2;
+                e->E2_len = fold_n;
+            } else {
+                fold_n = e->E1_len / 2;
+                fold_in = e->E1[e->c1];
+                fold_out = e->E1[1 - e->c1];
+                e->c1 = 1 - e->c1;
+                e->E1_len = fold_n;
+                if (fold_n == 1) {
+                    scale_vec = e->E2[e->c2];
+                    scale_n = e->E2_len;
+                }
+            }
+        }
+        const fe* ca = l->buf[l->cur][0];
+        const fe* cb = l->buf[l->cur][1];
+        const fe* E1 = e->E1[e->c1];
+        const fe* E2 = e->E2[e->c2];
+        int nested = e->E1_len != 1;
+        fe* res = result_slot(ctx, 3);
+        if (l->mode == COZK_MODE_REP3)
+            k_layer_round_small<2><<<1, RT, 0, ctx->stream>>>(ia, ib, oa, ob, len_in, r != nullptr, rr, fold_in, fold_out, fold_n, scale_vec, scale_n, ca, cb,
+                                                             l->len, E1, e->E1_len / 2, E2, e->E2_len, nested, res);
+        else
+            k_layer_round_small<1><<<1, RT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, len_in, r != nullptr, rr, fold_in, fold_out, fold_n, scale_vec, scale_n,
+                                                             ca, nullptr, l->len, E1, e->E1_len / 2, E2, e->E2_len, nested, res);
+        HIP_TRY(hipGetLastError());
+        fe sres[3];
+        fetch_fe(ctx, res, 3, sres);
+        fe ev[4] = {sres[0], Fr::sub(fe_from_u64x4(prev_claim), sres[0]), sres[1], sres[2]};
+        fe cf[4];
+        unipoly_from_evals(ev, 4, cf);
+        for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], out_coeffs + 4 * i);
+    });
+}
+
+// The whole round loop of Rep3BatchedCubicSumcheckWorker::prove_sumcheck (co-jolt/src/subprotocols/sumcheck.rs:
+// 96-131) for one layer: per round compute_cubic -> `cb` (the host sends the coefficients, receives the challenge
+// and the next claim) -> bind, then final_claims.  While the layer is large each round is its own launch
+// (cozk_layer_round); once it is down to ROUND_PERSIST_MAX elements the remaining rounds, the last bind and the
+// final claims run inside ONE resident kernel that exchanges sums and challenges with this thread through a
+// pinned mailbox (k_layer_rounds_persistent).  cb returns 0 on success; `next_claim` must already be this party's
+// additive share.  out_r = num_rounds x 4; final_claims = left.a, left.b, right.a, right.b.
+int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64_t claim[4], int num_rounds, cozk_round_cb cb,
+                            void* user, uint64_t* out_r, uint64_t final_claims[16]) {
+    if (!ctx || !l || !e || !claim || !cb || !final_claims || num_rounds < 0 || (num_rounds > 0 && !out_r)) return COZK_ERR_INVALID_ARG;
+    static const bool no_persist = getenv("COZK_NO_PERSIST") != nullptr;
+    uint64_t pc[4], rr[4], coeffs[16], nc[4];
+    memcpy(pc, claim, sizeof pc);
+    bool have_r = false;
+    int round = 0;
+    for (; round < num_rounds; round++) {
+        if (!no_persist && l->len <= ROUND_PERSIST_MAX && l->len >= 2) break;
+        int rc = cozk_layer_round(ctx, l, e, have_r ? rr : nullptr, pc, coeffs);
+        if (rc != COZK_OK) return rc;
+        if (cb(user, round, coeffs, rr, nc) != 0) {
+            ctx->last_error = "layer_prove_rounds: round callback failed";
+            return COZK_ERR_INTERNAL;
+        }
+        memcpy(out_r + 4 * round, rr, sizeof rr);
+        memcpy(pc, nc, sizeof pc);
+        have_r = true;
+    }
+    if (round == num_rounds) {  // every round ran as its own launch
+        if (num_rounds > 0) {
+            int rc = cozk_layer_bind(ctx, l, rr);
+            if (rc != COZK_OK) return rc;
+            rc = cozk_spliteq_bind(ctx, e, rr);
+            if (rc != COZK_OK) return rc;
+        }
+        return cozk_layer_final_claims(ctx, l, final_claims);
+    }
+    return cozk_guard(ctx, [&] {
+        const int nrem = num_rounds - round;
+        // both ping-pong buffers of the layer must hold the current length
+        for (int w = 0; w < 2; w++) {
+            if (w != l->cur && l->cap[w] < l->len) {
+                for (int c = 0; c < 2; c++) {
+                    if (l->buf[w][c]) ctx_dev_free(l->ctx, l->buf[w][c]);
+                    l->buf[w][c] = nullptr;
+                }
+                l->buf[w][0] = dev_alloc_fe(l->len);
+                if (l->mode == COZK_MODE_REP3) l->buf[w][1] = dev_alloc_fe(l->len);
+                l->cap[w] = l->len;
+            }
+        }
+        if (!ctx->mailbox) HIP_TRY(hipHostMalloc(&ctx->mailbox, sizeof(RoundMailbox), hipHostMallocMapped | hipHostMallocCoherent));
+        RoundMailbox* mb = (RoundMailbox*)ctx->mailbox;
+        memset(mb, 0, sizeof *mb);
+        std::atomic_thread_fence(std::memory_order_seq_cst);
+        fe r_first = have_r ? fe_from_u64x4(rr) : Fr::zero();
+        if (l->mode == COZK_MODE_REP3)
+            k_layer_rounds_persistent<2><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], l->buf[0][1], l->buf[1][0], l->buf[1][1], l->cur, l->len, e->E1[0], e->E1[1],
+                                                                   e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb);
+        else
+            k_layer_rounds_persistent<1><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], nullptr, l->buf[1][0], nullptr, l->cur, l->len, e->E1[0], e->E1[1], e->c1,
+                                                                   e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb);
+        HIP_TRY(hipGetLastError());
+        volatile uint32_t* res_seq = &mb->res_seq;
+        volatile uint32_t* status = &mb->status;
+        auto give_up = [&](const char* why) {
+            *(volatile uint32_t*)&mb->abort = 1;
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            (void)hipStreamSynchronize(ctx->stream);
+            throw CozkError(COZK_ERR_INTERNAL, why);
+        };
+        auto wait_result = [&](uint32_t want) {
+            auto t0 = std::chrono::steady_clock::now();
+            uint64_t spins = 0;
+            while (*res_seq != want) {
+                if (*status) give_up("layer_prove_rounds: the resident kernel gave up waiting for the host");
+                __builtin_ia32_pause();
+                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(15))
+                    give_up("layer_prove_rounds: no result from the resident kernel");
+            }
+            std::atomic_thread_fence(std::memory_order_acquire);
+        };
+        for (int j = 0; j < nrem; j++) {
+            wait_result((uint32_t)j + 1);
+            fe s0 = mb->res[0], s2 = mb->res[1], s3 = mb->res[2];
+            fe ev[4] = {s0, Fr::sub(fe_from_u64x4(pc), s0), s2, s3};
+            fe cf[4];
+            unipoly_from_evals(ev, 4, cf);
+            for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], coeffs + 4 * i);
+            if (cb(user, round + j, coeffs, rr, nc) != 0) give_up("layer_prove_rounds: round callback failed");
+            memcpy(out_r + 4 * (round + j), rr, sizeof rr);
+            memcpy(pc, nc, sizeof pc);
+            mb->r = fe_from_u64x4(rr);
+            std::atomic_thread_fence(std::memory_order_release);
+            *(volatile uint32_t*)&mb->cmd_seq = (uint32_t)j + 1;
+        }
+        wait_result((uint32_t)nrem + 1);
+        for (int k = 0; k < 4; k++) fe_to_u64x4(mb->res[k], final_claims + 4 * k);
+        if (getenv("COZK_TRACE_ROUNDS"))
+            fprintf(stderr, "[mailbox] %d rounds: device us/round: wait %.1f bind %.1f cubic %.1f publish %.1f\n", nrem,
+                    mb->dbg[0] / 100.0 / (nrem + 1), mb->dbg[1] / 100.0 / (nrem + 1), mb->dbg[2] / 100.0 / nrem, mb->dbg[3] / 100.0 / nrem);
+        // mirror the kernel's bookkeeping: one bind per remaining round (+ the pending one it started with)
+        int binds = nrem + (have_r ? 1 : 0);
+        for (int b = 0; b < binds; b++) {
+            l->len = 2 * ((l->len + 3) / 4);
+            l->cur = 1 - l->cur;
+            if (e->E1_len == 1) {
+                e->E2_len /= 2;
+                e->c2 = 1 - e->c2;
+            } else {
+                e->E1_len /= 2;
+                e->c1 = 1 - e->c1;
+            }
+        }
     });
 }
 

@@ -269,6 +269,48 @@ class Rep3DenseInterleavedPolynomial:
         self.ctx.check(self.ctx._l.cozk_layer_compute_cubic(self.ctx.h, self.h, eq_poly.h, pc.ctypes.data, out.ctypes.data))
         return mont_limbs_to_int(out)
 
+    def round(self, eq_poly, r, previous_round_claim):
+        """one prove_sumcheck round in one call: bind layer + eq with the previous challenge r (None in round 0),
+        then compute_cubic -> 4 additive coefficient shares"""
+        pc = _fr(previous_round_claim)
+        rr = _fr(r) if r is not None else None
+        out = np.zeros((4, 4), dtype=np.uint64)
+        self.ctx.check(self.ctx._l.cozk_layer_round(self.ctx.h, self.h, eq_poly.h, rr.ctypes.data if rr is not None else None,
+                                                    pc.ctypes.data, out.ctypes.data))
+        return mont_limbs_to_int(out)
+
+    def prove_rounds(self, eq_poly, claim, num_rounds, exchange):
+        """the whole prove_sumcheck round loop (cozk_layer_prove_rounds): `exchange(round, coeffs) -> (r, next_claim)` is
+        the host's star exchange.  Returns (challenges, (left, right) final claims)."""
+        cb_t = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_uint64),
+                                ctypes.POINTER(ctypes.c_uint64))
+        err = []
+
+        def _cb(_u, rnd, coeffs, r_out, nc_out):
+            try:
+                cf = mont_limbs_to_int(np.ctypeslib.as_array(coeffs, shape=(4, 4)).copy())
+                r, nc = exchange(rnd, cf)
+                rr, cc = _fr(r), _fr(nc)
+                for i in range(4):
+                    r_out[i] = int(rr.reshape(-1)[i])
+                    nc_out[i] = int(cc.reshape(-1)[i])
+                return 0
+            except Exception as e:  # never unwind into C
+                err.append(e)
+                return 1
+
+        cb = cb_t(_cb)
+        pc = _fr(claim)
+        rs = np.zeros((max(1, num_rounds), 4), dtype=np.uint64)
+        fc = np.zeros((4, 4), dtype=np.uint64)
+        rc = self.ctx._l.cozk_layer_prove_rounds(self.ctx.h, self.h, eq_poly.h, pc.ctypes.data, num_rounds, cb, None, rs.ctypes.data, fc.ctypes.data)
+        if err:
+            raise err[0]
+        self.ctx.check(rc)
+        f = mont_limbs_to_int(fc)
+        left, right = ((f[0], f[1]), (f[2], f[3])) if self.mode == L.MODE_REP3 else (f[0], f[2])
+        return mont_limbs_to_int(rs)[:num_rounds], (left, right)
+
     def final_claims(self, party_id=None):
         out = np.zeros((4, 4), dtype=np.uint64)
         self.ctx.check(self.ctx._l.cozk_layer_final_claims(self.ctx.h, self.h, out.ctypes.data))

@@ -213,6 +213,21 @@ int cozk_layer_bind(cozk_ctx* ctx, cozk_layer* l, const uint64_t r[4]);
  * coefficient shares (low -> high) of the round polynomial */
 int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,
                              const uint64_t prev_claim[4], uint64_t out_coeffs[16]);
+/* one round of Rep3BatchedCubicSumcheckWorker::prove_sumcheck (co-jolt/src/subprotocols/sumcheck.rs:107-122) in
+ * one call: Rep3Bindable::bind + SplitEqPolynomial::bind with the previous round's challenge r (NULL in the first
+ * round), then compute_cubic; small layers run as a single launch */
+int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* eq, const uint64_t* r,
+                     const uint64_t prev_claim[4], uint64_t out_coeffs[16]);
+/* the whole round loop of prove_sumcheck (sumcheck.rs:96-131) for one layer, the host's transport as a callback:
+ * per round cb(user, round, coeffs[4x4], r_out[4], next_claim_out[4]) sends the round polynomial's coefficient
+ * shares and returns the challenge and this party's additive share of the next claim (0 = ok).  Large rounds
+ * are one launch each; the tail of the layer (<= 2048 elements) runs in one resident kernel that trades sums and
+ * challenges with the host through pinned memory.  out_r = num_rounds x 4; final_claims = L.a, L.b, R.a, R.b */
+typedef int (*cozk_round_cb)(void* user, int round, const uint64_t coeffs[16], uint64_t r_out[4],
+                             uint64_t next_claim_out[4]);
+int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* eq, const uint64_t claim[4],
+                            int num_rounds, cozk_round_cb cb, void* user, uint64_t* out_r,
+                            uint64_t final_claims[16]);
 /* raw sums g(0), g(2), g(3) of compute_cubic (12 u64) for worker sub-nets: the coordinator inserts
  * claim - g(0) itself, as for the reference's primary sumcheck (instruction_lookups/worker.rs:593-597) */
 int cozk_layer_compute_cubic_evals(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,

@@ -138,6 +138,81 @@ def test_layer_bind_and_cubic_all_rounds(cozk, ctx, mode, length):
 
 
 @pytest.mark.parametrize("mode", ["rep3", "plain"])
+@pytest.mark.parametrize("length", [4, 6, 96, 2048 + 8, 1 << 15, (1 << 15) + 12])
+def test_layer_round_fused_equals_separate_calls(cozk, ctx, mode, length):
+    """cozk_layer_round (bind + eq bind + compute_cubic per call; single-launch kernel for layers <= 8192 elements,
+    so the two larger sizes cross from the separate-kernel path into it) gives the same round messages and the
+    same bound layer as the separate calls; the small sizes are also checked against the oracle"""
+    rng = O.SplitMix64(length * 5 + (mode == "plain"))
+    coeffs = _shares(rng, length, mode)
+    nodes = (length + 1) // 2
+    nv = max(0, (nodes - 1).bit_length())
+    w = [rng.field() for _ in range(nv)]
+    fused = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+    sep = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+    eq_f, eq_s = cozk.SplitEqPolynomial(ctx, w), cozk.SplitEqPolynomial(ctx, w)
+    small = length <= 4096
+    ref, ref_eq = list(coeffs), O.SplitEq(w)
+    r = None
+    for _ in range(nv):
+        claim = rng.field()
+        if r is not None:
+            sep.bind(r)
+            eq_s.bind(r)
+            if small:
+                ref = O.interleaved_bind(ref, r)
+                ref_eq.bind(r)
+        got = fused.round(eq_f, r, claim)
+        assert got == sep.compute_cubic(eq_s, claim)
+        assert eq_f.lens() == eq_s.lens()
+        if small:
+            assert got == O.interleaved_compute_cubic(ref, ref_eq, claim)
+        r = rng.field()
+    if r is not None:
+        fused.bind(r)
+        sep.bind(r)
+    assert fused.coeffs() == sep.coeffs()
+
+
+@pytest.mark.parametrize("mode", ["rep3", "plain"])
+@pytest.mark.parametrize("length", [4, 6, 96, 2048, 4096 + 8, 1 << 14])
+def test_layer_prove_rounds_matches_separate_calls(cozk, ctx, mode, length):
+    """cozk_layer_prove_rounds (whole round loop behind the ABI; per-round launches above 2048 elements, then the
+    resident mailbox kernel down to the final claims) sends the same round polynomials and ends in the same final
+    claims as compute_cubic / bind / final_claims called one by one"""
+    rng = O.SplitMix64(length * 7 + (mode == "plain"))
+    coeffs = _shares(rng, length, mode)
+    nodes = (length + 1) // 2
+    nv = max(0, (nodes - 1).bit_length())
+    w = [rng.field() for _ in range(nv)]
+    claim0 = rng.field()
+    rs = [rng.field() for _ in range(nv)]
+    claims = [rng.field() for _ in range(nv)]
+    sep = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+    eq_s = cozk.SplitEqPolynomial(ctx, w)
+    expected, c = [], claim0
+    for j in range(nv):
+        expected.append(sep.compute_cubic(eq_s, c))
+        sep.bind(rs[j])
+        eq_s.bind(rs[j])
+        c = claims[j]
+    one = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+    eq_o = cozk.SplitEqPolynomial(ctx, w)
+    seen = []
+
+    def exchange(rnd, cf):
+        seen.append(cf)
+        return rs[rnd], claims[rnd]
+
+    got_r, (left, right) = one.prove_rounds(eq_o, claim0, nv, exchange)
+    assert seen == expected
+    assert got_r == rs
+    if nv:
+        assert (left, right) == sep.final_claims()
+        assert one.coeffs() == sep.coeffs()
+
+
+@pytest.mark.parametrize("mode", ["rep3", "plain"])
 def test_layer_output_local_masks_and_claimed_outputs(cozk, ctx, mode):
     rng = O.SplitMix64(31)
     coeffs = _shares(rng, 64, mode)
