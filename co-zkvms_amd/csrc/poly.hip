@@ -445,7 +445,10 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
             }
             return;
         }
-        // cubic sums of this round
+        // cubic sums of this round.  The serial chain is what a tiny round costs (one dependent Fr product is
+        // ~1.3 us on a lone wave), so the three evaluation points go to three groups of five waves: a lane does
+        // ONE (chunk, point) term -- l x r and e x scale side by side, then their product -- and the three sums
+        // come out of one reduction pass.
         const fe *ca = la[lcur], *cb = lb[lcur];
         const fe *E1 = e1[c1], *E2 = e2[c2];
         const bool nested = E1_len != 1;
@@ -453,49 +456,59 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
         size_t nch = (len + 3) / 4;
         size_t limit = nested ? E1_half * E2_len : E2_len / 2;
         if (nch > limit) nch = limit;
-        fe s0 = Fr::zero(), s2 = Fr::zero(), s3 = Fr::zero();
-        for (size_t c = threadIdx.x; c < nch; c += RT) {
-            fe e[3];
-            fe scale = Fr::zero();
-            if (nested) {
-                size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
-                eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
-                scale = fe_load(E2 + x2);
-            } else {
-                eq3(fe_load(E2 + 2 * c), fe_load(E2 + 2 * c + 1), e);
+        const int wave = threadIdx.x >> 6;
+        const int pt = wave / 5;  // 0, 1, 2 = evaluation at 0, 2, 3; wave 15 idles
+        fe acc = Fr::zero();
+        if (pt < 3) {
+            for (size_t c = threadIdx.x - 320 * pt; c < nch; c += 320) {
+                fe e0, e1v, ek;
+                if (nested) {
+                    size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+                    e0 = fe_load(E1 + 2 * x1);
+                    e1v = fe_load(E1 + 2 * x1 + 1);
+                } else {
+                    e0 = fe_load(E2 + 2 * c);
+                    e1v = fe_load(E2 + 2 * c + 1);
+                }
+                Sh<NC> l0 = sh_load_or_zero<NC>(ca, cb, 4 * c, len), r0 = sh_load_or_zero<NC>(ca, cb, 4 * c + 1, len);
+                Sh<NC> lk = l0, rk = r0;
+                ek = e0;
+                if (pt > 0) {
+                    Sh<NC> l1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 2, len), r1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 3, len);
+                    Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
+                    fe me = Fr::sub(e1v, e0);
+                    lk = sh_add<NC>(l1, ml);
+                    rk = sh_add<NC>(r1, mr);
+                    ek = Fr::add(e1v, me);
+                    if (pt == 2) {
+                        lk = sh_add<NC>(lk, ml);
+                        rk = sh_add<NC>(rk, mr);
+                        ek = Fr::add(ek, me);
+                    }
+                }
+                fe lr = sh_local_mul<NC>(lk, rk);
+                // same association as k_layer_cubic ((l x r) e) scale: field products are exact, any order agrees
+                fe es = nested ? Fr::mul(ek, fe_load(E2 + c / E1_half)) : ek;
+                acc = Fr::add(acc, Fr::mul(lr, es));
             }
-            Sh<NC> l0 = sh_load_or_zero<NC>(ca, cb, 4 * c, len), r0 = sh_load_or_zero<NC>(ca, cb, 4 * c + 1, len);
-            Sh<NC> l1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 2, len), r1 = sh_load_or_zero<NC>(ca, cb, 4 * c + 3, len);
-            Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
-            Sh<NC> l2 = sh_add<NC>(l1, ml), r2 = sh_add<NC>(r1, mr);
-            Sh<NC> l3 = sh_add<NC>(l2, ml), r3 = sh_add<NC>(r2, mr);
-            fe t0 = Fr::mul(sh_local_mul<NC>(l0, r0), e[0]);
-            fe t2 = Fr::mul(sh_local_mul<NC>(l2, r2), e[1]);
-            fe t3 = Fr::mul(sh_local_mul<NC>(l3, r3), e[2]);
-            if (nested) {
-                t0 = Fr::mul(t0, scale);
-                t2 = Fr::mul(t2, scale);
-                t3 = Fr::mul(t3, scale);
-            }
-            s0 = Fr::add(s0, t0);
-            s2 = Fr::add(s2, t2);
-            s3 = Fr::add(s3, t3);
         }
-        s0 = fr_block_sum(s0, sh16);
-        s2 = fr_block_sum(s2, sh16);
-        s3 = fr_block_sum(s3, sh16);
+        acc = fr_wave_sum(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) sh16[wave] = acc;
+        __syncthreads();
         {
             long long t = wall_clock64();
             tk_cubic += t - tk0;
             tk0 = t;
         }
-        if (threadIdx.x == 0) {
-            fe v[3] = {s0, s2, s3};
-            for (int k = 0; k < 3; k++) fe_store(&mb->res[k], v[k]);
+        if (threadIdx.x < 3) {
+            fe v = sh16[5 * threadIdx.x];
+            for (int i = 1; i < 5; i++) v = Fr::add(v, sh16[5 * threadIdx.x + i]);
+            fe_store(&mb->res[threadIdx.x], v);
             __threadfence_system();
-            __hip_atomic_store(&mb->res_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(&mb->res_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
         {
             long long t = wall_clock64();
             tk_pub += t - tk0;
