@@ -707,7 +707,8 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
         HIP_TRY(hipStreamSynchronize(st));  // descs is a stack vector
         uint32_t wgs = (uint32_t)((max_n + 4095) / 4096);  // >= 4096 scalars per workgroup (measured: 64 beats 16 workgroups 2x)
         if (wgs < 1) wgs = 1;
-        if (wgs > 64) wgs = 64;
+        static const uint32_t wg_cap = getenv("COZK_SCATTER_WGS") ? (uint32_t)atoi(getenv("COZK_SCATTER_WGS")) : 64u;
+        if (wgs > wg_cap) wgs = wg_cap;
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
             KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist)));
