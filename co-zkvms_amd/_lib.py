@@ -103,6 +103,7 @@ SIGNATURES = {
     "cozk_layer_clone": (_i, [_vp, _vp, _pp]),
     "cozk_layer_bind": (_i, [_vp, _vp, _vp]),
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
+    "cozk_ctx_set_resident_rounds": (_i, [_vp, _i]),
     "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cozk_layer_prove_rounds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cozk_layer_final_claims": (_i, [_vp, _vp, _vp]),

@@ -156,12 +156,21 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
     ctx->scratch.release();
     ctx->scratch2.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
-    if (ctx->msm_pinned) (void)hipHostFree(ctx->msm_pinned);
     if (ctx->round_flag) (void)hipHostFree(ctx->round_flag);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
-    if (ctx->msm_event) (void)hipEventDestroy(ctx->msm_event);
+    if (ctx->stream2) {
+        (void)hipStreamSynchronize(ctx->stream2);
+        (void)hipStreamDestroy(ctx->stream2);
+    }
     (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return COZK_OK;
+}
+
+// see cozk.h: the resident round kernel must not be used by provers whose progress depends on each other's GPU work
+int cozk_ctx_set_resident_rounds(cozk_ctx* ctx, int enable) {
+    if (!ctx) return COZK_ERR_INVALID_ARG;
+    ctx->resident_rounds = enable != 0;
     return COZK_OK;
 }
 

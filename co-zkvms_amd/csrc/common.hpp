@@ -56,11 +56,30 @@ struct DevBuf {
     T* as() { return reinterpret_cast<T*>(p); }
 };
 
-struct MsmWorkspace {
-    DevBuf hist, off0, refs, offA, offB, partA, partB, bsum, chunk, grp, out, ptrs, exc;
+// what the sort phase of one MSM launch set produces (two of them: the sort of set k+1 overlaps the accumulation of set k)
+struct MsmSortWs {
+    DevBuf hist, off0, refs, offA, ptrs;
+    uint32_t* max_pinned = nullptr;   // [0] fullest bucket (read back behind max_event); + 64: polynomial descriptors (H2D staging)
+    hipEvent_t max_event = nullptr, done = nullptr, consumed = nullptr;
     void release() {
-        for (DevBuf* b : {&hist, &off0, &refs, &offA, &offB, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs, &exc})
-            b->release();
+        for (DevBuf* b : {&hist, &off0, &refs, &offA, &ptrs}) b->release();
+        if (max_pinned) (void)hipHostFree(max_pinned);
+        max_pinned = nullptr;
+        for (hipEvent_t* e : {&max_event, &done, &consumed}) {
+            if (*e) (void)hipEventDestroy(*e);
+            *e = nullptr;
+        }
+    }
+};
+struct MsmWorkspace {
+    MsmSortWs sort[2];
+    DevBuf offB, offC, partA, partB, bsum, chunk, grp, out, ptrs, exc;
+    hipEvent_t fork = nullptr;
+    void release() {
+        for (MsmSortWs& s : sort) s.release();
+        for (DevBuf* b : {&offB, &offC, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs, &exc}) b->release();
+        if (fork) (void)hipEventDestroy(fork);
+        fork = nullptr;
     }
 };
 
@@ -123,6 +142,7 @@ struct DevPool {
 struct cozk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;  // side stream: MSM sort phase of the next launch set
     DevPool pool;
     std::string last_error;
     MsmWorkspace msm_ws;
@@ -130,11 +150,10 @@ struct cozk_ctx {
     DevBuf scratch2;
     void* pinned = nullptr;  // pinned host staging for small D2H results
     size_t pinned_cap = 0;
+    bool resident_rounds = true;     // cozk_ctx_set_resident_rounds
     void* mailbox = nullptr;         // fine-grained pinned host memory shared with the resident round kernel
     uint32_t* round_flag = nullptr;  // pinned word a stream write bumps behind each round's finishing kernel
     uint32_t round_seq = 0;
-    uint32_t* msm_pinned = nullptr;  // largest bucket of the current MSM launch set (read back behind an event)
-    hipEvent_t msm_event = nullptr;
     // timing of the dominant kernel (bench roofline): accumulated HIP-event time of the
     // bucket-accumulation launches on this stream
     bool prof_enabled = false;

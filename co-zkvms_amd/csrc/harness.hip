@@ -593,6 +593,9 @@ int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out) {
                 int rc = cozk_ctx_create(dev, &ps.ctx);
                 if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
                 ps.own_ctx = true;
+                // several participants driven from this one process wait for each other's round messages: no
+                // resident round kernels (cozk_ctx_set_resident_rounds)
+                if (h->nparties * W > 1) cozk_ctx_set_resident_rounds(ps.ctx, 0);
                 HIP_TRY(hipSetDevice(ps.ctx->device));
                 if (W > 1) setup_participant_split(h, ps, w);
                 else setup_party(h, ps);

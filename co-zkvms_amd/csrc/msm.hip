@@ -594,16 +594,6 @@ static void build_window_table(cozk_ctx* ctx, cozk_bases* b) {
     HIP_TRY(hipGetLastError());
 }
 
-template <int KIND>
-static void launch_hist(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* hist, int grouped) {
-    k_msm_hist<KIND><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(sc, n, hist, grouped);
-}
-template <int KIND>
-static void launch_scatter(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* cursor, uint32_t* refs, int grouped,
-                           uint32_t table_n, uint32_t base_off) {
-    k_msm_scatter<KIND><<<cdiv(n, TPB), TPB, 0, ctx->stream>>>(sc, n, cursor, refs, grouped, table_n, base_off);
-}
-
 #define KIND_DISPATCH(kind, CALL)                                              \
     switch (kind) {                                                            \
         case COZK_SCALAR_FR: { constexpr int K = COZK_SCALAR_FR; CALL; } break;   \
@@ -615,106 +605,109 @@ static void launch_scatter(cozk_ctx* ctx, const void* sc, size_t n, uint32_t* cu
         default: throw CozkError(COZK_ERR_INVALID_ARG, "unknown scalar kind");    \
     }
 
-// P MSMs: polynomial p runs over bases[offsets[p] .. offsets[p]+ns[p]); scalars[p] = device pointer of
-// kinds[p]; results -> d_out[P]
-void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, const size_t* ns,
-                    const void* const* scalars, const int* kinds, size_t P, g1_xyzz* dense_out) {
+// One launch set = P MSMs (polynomial p runs over bases[offsets[p] .. offsets[p]+ns[p]); scalars[p] = device
+// pointer of kinds[p]) in two phases that msm_batch pipelines on two streams:
+//   msm_sort        digits -> histogram -> offsets -> sorted point references (LDS atomics, HBM writes)
+//   msm_accumulate  gather + fold levels -> one XYZZ sum per bucket in `dense_out` (integer ALU)
+// The phases stress different units, so the sort of set k+1 hides behind the accumulation of set k.
+struct MsmSetPlan {
+    uint32_t P = 0, G = 1, nb = 0, L0 = 8;
+    uint64_t M = 0, bound = 0, maxseg0 = 0;
+    bool pre = false;
+};
+
+static MsmSetPlan msm_plan(const cozk_bases* bases, const size_t* offsets, const size_t* ns, const int* kinds, size_t P) {
     COZK_REQUIRE(P >= 1, "msm: empty batch");
     COZK_REQUIRE((uint64_t)bases->n * (uint64_t)bases->nwin < (1ull << 31), "msm: table too large for 31-bit refs");
-    MsmWorkspace& ws = ctx->msm_ws;
-    hipStream_t st = ctx->stream;
-    const bool pre = bases->nwin == 16;
-    const uint32_t G = pre ? 1u : 16u;
-    const uint32_t ngroups = (uint32_t)P * G;
-    const uint32_t nb = ngroups * NB;
-    uint64_t M = 0, bound = 0;
+    MsmSetPlan pl;
+    pl.P = (uint32_t)P;
+    pl.pre = bases->nwin == 16;
+    pl.G = pl.pre ? 1u : 16u;
+    pl.nb = (uint32_t)P * pl.G * NB;
     for (size_t p = 0; p < P; p++) {
         COZK_REQUIRE(offsets[p] + ns[p] <= bases->n, "msm: base slice out of range");
         uint64_t m = (uint64_t)ns[p] * kind_nwin(kinds[p]);
-        M += m;
-        if (m > bound) bound = m;
+        pl.M += m;
+        if (m > pl.bound) pl.bound = m;
     }
-    if (M == 0) {
-        HIP_TRY(hipMemsetAsync(dense_out, 0, (size_t)nb * sizeof(g1_xyzz), st));  // all buckets = identity (zz = 0)
-        return;
-    }
-    COZK_REQUIRE(M < (1ull << 32), "msm: batch too large (reference count exceeds 32 bits)");
+    COZK_REQUIRE(pl.M < (1ull << 32), "msm: batch too large (reference count exceeds 32 bits)");
     // segment length of level 0: aim at >= ~2^18 lanes, clamp to [8, 64] (measured: 256-long segments leave
     // too few waves per SIMD and run the gather kernel 14 % slower)
-    uint32_t L0 = (uint32_t)(M >> 18);
+    uint32_t L0 = (uint32_t)(pl.M >> 18);
     if (L0 < 8) L0 = 8;
     if (L0 > 64) L0 = 64;
-    // upper levels fold <= L1 partial sums per lane.  The chain is serial (a full XYZZ addition per step, ~25 us
-    // when a wave runs alone), so it is kept short: 64-long chains made the fold of the one heavy bucket of a
-    // u16 / u32 / flag column (the carry digit: n/2 references) cost as much as its whole gather pass.
-    const uint32_t L1 = 8;
+    pl.L0 = L0;
+    pl.maxseg0 = pl.M / L0 + pl.nb;
+    return pl;
+}
 
-    ws.hist.reserve((size_t)(nb + 2) * 4);
-    ws.off0.reserve((size_t)(nb + 1) * 4);
-    ws.offA.reserve((size_t)(nb + 1) * 4);
-    ws.offB.reserve((size_t)(nb + 1) * 4);
-    ws.refs.reserve((size_t)M * 4);
-    const uint64_t maxseg0 = M / L0 + nb;
-    // segment counts obey x_{k+1} = x_k / L1 + nb <= max(x_0, 2 nb): size both ping-pong buffers for that
-    const uint64_t maxpart = maxseg0 > 2ull * nb ? maxseg0 : 2ull * nb;
-    ws.partA.reserve((size_t)maxpart * sizeof(g1_xyzz));
-    ws.partB.reserve((size_t)maxpart * sizeof(g1_xyzz));
-
-    uint32_t* hist = ws.hist.as<uint32_t>();
-    uint32_t* off0 = ws.off0.as<uint32_t>();
-    uint32_t* refs = ws.refs.as<uint32_t>();
+static void msm_scan(hipStream_t st, uint32_t* bsums, uint32_t nb, bool from_offsets, const uint32_t* in, uint32_t L, uint32_t* off, uint32_t* cursor) {
     const uint32_t nscan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
-    ws.ptrs.reserve((size_t)nscan_blocks * 4 + P * sizeof(MsmPolyDesc) + 64);
-    uint32_t* bsums = ws.ptrs.as<uint32_t>();
+    if (from_offsets) {
+        k_scan_sums<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+        k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
+        k_scan_final<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+    } else {
+        k_scan_sums<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+        k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
+        k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+    }
+}
+
+// sort phase on stream `st` into the sort workspace `sw`
+static void msm_sort(cozk_ctx* ctx, hipStream_t st, MsmSortWs& sw, const MsmSetPlan& pl, const cozk_bases* bases, const size_t* offsets,
+                     const size_t* ns, const void* const* scalars, const int* kinds) {
+    const uint32_t nb = pl.nb, G = pl.G;
+    const size_t P = pl.P;
+    sw.hist.reserve((size_t)(nb + 2) * 4);
+    sw.off0.reserve((size_t)(nb + 1) * 4);
+    sw.offA.reserve((size_t)(nb + 1) * 4);
+    sw.refs.reserve((size_t)pl.M * 4);
+    uint32_t* hist = sw.hist.as<uint32_t>();
+    uint32_t* off0 = sw.off0.as<uint32_t>();
+    uint32_t* refs = sw.refs.as<uint32_t>();
+    const uint32_t nscan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
+    sw.ptrs.reserve((size_t)nscan_blocks * 4 + P * sizeof(MsmPolyDesc) + 64);
+    uint32_t* bsums = sw.ptrs.as<uint32_t>();
     MsmPolyDesc* d_descs = reinterpret_cast<MsmPolyDesc*>(((uintptr_t)(bsums + nscan_blocks) + 15) & ~(uintptr_t)15);
-    auto scan = [&](bool from_offsets, const uint32_t* in, uint32_t L, uint32_t* off, uint32_t* cursor) {
-        if (from_offsets) {
-            k_scan_sums<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
-            k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
-            k_scan_final<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
-        } else {
-            k_scan_sums<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
-            k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
-            k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
-        }
-    };
     HIP_TRY(hipMemsetAsync(hist, 0, (size_t)(nb + 2) * 4, st));
     uint32_t* d_maxcnt = hist + nb + 1;  // not touched by the scans (they own hist[0..nb])
-    if (!ctx->msm_pinned) HIP_TRY(hipHostMalloc((void**)&ctx->msm_pinned, 64, hipHostMallocDefault));
-    if (!ctx->msm_event) HIP_TRY(hipEventCreateWithFlags(&ctx->msm_event, hipEventDisableTiming));
+    if (!sw.max_pinned) HIP_TRY(hipHostMalloc((void**)&sw.max_pinned, 64 + 64 * sizeof(MsmPolyDesc), hipHostMallocDefault));
+    if (!sw.max_event) HIP_TRY(hipEventCreateWithFlags(&sw.max_event, hipEventDisableTiming));
     // after the histogram: fullest bucket -> pinned host word, behind an event the host waits on only when it
     // sizes the fold levels (by then the GPU is inside the long gather pass, so the queue never drains)
     auto read_back_max = [&] {
         k_max_u32<<<std::min<uint32_t>(cdiv(nb, 256), 1024u), 256, 0, st>>>(hist, nb, d_maxcnt);
-        HIP_TRY(hipMemcpyAsync(ctx->msm_pinned, d_maxcnt, 4, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipEventRecord(ctx->msm_event, st));
+        HIP_TRY(hipMemcpyAsync(sw.max_pinned, d_maxcnt, 4, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipEventRecord(sw.max_event, st));
     };
-    if (pre) {
-        // LDS-privatised counting sort: one launch per scalar kind, grid = (workgroups per polynomial, polynomials)
-        std::vector<MsmPolyDesc> descs;
+    if (pl.pre) {
+        // LDS-privatised counting sort: one launch per scalar kind, grid = (workgroups per polynomial, polynomials).
+        // The descriptors travel through pinned memory owned by the workspace (no host sync here).
+        MsmPolyDesc* h_descs = reinterpret_cast<MsmPolyDesc*>(reinterpret_cast<char*>(sw.max_pinned) + 64);
+        COZK_REQUIRE(P <= 64, "msm: too many polynomials in one launch set");
+        uint32_t nd = 0;
         std::vector<std::pair<int, std::pair<uint32_t, uint32_t>>> runs;  // kind -> (first desc, count)
         size_t max_n = 0;
         for (int kind = 0; kind <= COZK_SCALAR_I64; kind++) {
-            uint32_t first = (uint32_t)descs.size();
+            uint32_t first = nd;
             for (size_t p = 0; p < P; p++)
                 if (kinds[p] == kind && ns[p]) {
-                    descs.push_back(MsmPolyDesc{scalars[p], (uint32_t)ns[p], (uint32_t)offsets[p], (uint32_t)p, 0});
+                    h_descs[nd++] = MsmPolyDesc{scalars[p], (uint32_t)ns[p], (uint32_t)offsets[p], (uint32_t)p, 0};
                     if (ns[p] > max_n) max_n = ns[p];
                 }
-            if (descs.size() > first) runs.push_back({kind, {first, (uint32_t)descs.size() - first}});
+            if (nd > first) runs.push_back({kind, {first, nd - first}});
         }
-        HIP_TRY(hipMemcpyAsync(d_descs, descs.data(), descs.size() * sizeof(MsmPolyDesc), hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));  // descs is a stack vector
+        HIP_TRY(hipMemcpyAsync(d_descs, h_descs, nd * sizeof(MsmPolyDesc), hipMemcpyHostToDevice, st));
         uint32_t wgs = (uint32_t)((max_n + 4095) / 4096);  // >= 4096 scalars per workgroup (measured: 64 beats 16 workgroups 2x)
         if (wgs < 1) wgs = 1;
-        static const uint32_t wg_cap = getenv("COZK_SCATTER_WGS") ? (uint32_t)atoi(getenv("COZK_SCATTER_WGS")) : 64u;
-        if (wgs > wg_cap) wgs = wg_cap;
+        if (wgs > 64) wgs = 64;
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
             KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist)));
         }
         read_back_max();
-        scan(false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
+        msm_scan(st, bsums, nb, false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
             KIND_DISPATCH(r.first, (k_msm_scatter_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist, refs, (uint32_t)bases->n)));
@@ -722,27 +715,49 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
     } else {
         for (size_t p = 0; p < P; p++) {
             uint32_t* h = hist + (size_t)p * G * NB;
-            if (ns[p]) KIND_DISPATCH(kinds[p], launch_hist<K>(ctx, scalars[p], ns[p], h, 1));
+            if (ns[p]) KIND_DISPATCH(kinds[p], (k_msm_hist<K><<<cdiv(ns[p], TPB), TPB, 0, st>>>(scalars[p], ns[p], h, 1)));
         }
         read_back_max();
-        scan(false, hist, 1, off0, hist);
+        msm_scan(st, bsums, nb, false, hist, 1, off0, hist);
         for (size_t p = 0; p < P; p++) {
             uint32_t* cur = hist + (size_t)p * G * NB;
-            if (ns[p]) KIND_DISPATCH(kinds[p], launch_scatter<K>(ctx, scalars[p], ns[p], cur, refs, 1, (uint32_t)bases->n,
-                                                               (uint32_t)offsets[p]));
+            if (ns[p])
+                KIND_DISPATCH(kinds[p], (k_msm_scatter<K><<<cdiv(ns[p], TPB), TPB, 0, st>>>(scalars[p], ns[p], cur, refs, 1, (uint32_t)bases->n,
+                                                                                         (uint32_t)offsets[p])));
         }
     }
-    // level 0
-    uint32_t* offA = ws.offA.as<uint32_t>();
-    uint32_t* offB = ws.offB.as<uint32_t>();
-    scan(true, off0, L0, offA, nullptr);
+    msm_scan(st, bsums, nb, true, off0, pl.L0, sw.offA.as<uint32_t>(), nullptr);  // level-0 segment offsets
+    HIP_TRY(hipGetLastError());
+}
+
+// accumulate phase on the context's stream; reads the sort workspace `sw` (its producer must have been waited for)
+static void msm_accumulate(cozk_ctx* ctx, MsmSortWs& sw, const MsmSetPlan& pl, const cozk_bases* bases, const size_t* ns, const int* kinds,
+                           g1_xyzz* dense_out) {
+    MsmWorkspace& ws = ctx->msm_ws;
+    hipStream_t st = ctx->stream;
+    const uint32_t nb = pl.nb, L0 = pl.L0;
+    // upper levels fold <= L1 partial sums per lane.  The chain is serial (a full XYZZ addition per step, ~25 us
+    // when a wave runs alone), so it is kept short: 64-long chains made the fold of the one heavy bucket of a
+    // u16 / u32 / flag column (the carry digit: n/2 references) cost as much as its whole gather pass.
+    const uint32_t L1 = 8;
+    const uint64_t maxseg0 = pl.maxseg0;
+    // segment counts obey x_{k+1} = x_k / L1 + nb <= max(x_0, 2 nb): size both ping-pong buffers for that
+    const uint64_t maxpart = maxseg0 > 2ull * nb ? maxseg0 : 2ull * nb;
+    ws.partA.reserve((size_t)maxpart * sizeof(g1_xyzz));
+    ws.partB.reserve((size_t)maxpart * sizeof(g1_xyzz));
+    ws.offB.reserve((size_t)(nb + 1) * 4);
+    ws.offC.reserve((size_t)(nb + 1) * 4);
+    ws.ptrs.reserve((size_t)((nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK) * 4 + 64);
+    uint32_t* refs = sw.refs.as<uint32_t>();
+    uint32_t* off0 = sw.off0.as<uint32_t>();
+    uint32_t* offA = sw.offA.as<uint32_t>();
     hipEvent_t e0 = nullptr, e1 = nullptr;
     if (ctx->prof_enabled) {
         HIP_TRY(hipEventCreate(&e0));
         HIP_TRY(hipEventCreate(&e1));
         HIP_TRY(hipEventRecord(e0, st));
     }
-    if (pre) {
+    if (pl.pre) {
         ws.exc.reserve((size_t)(maxseg0 + 2) * 4);
         uint32_t* exc = ws.exc.as<uint32_t>();
         HIP_TRY(hipMemsetAsync(exc, 0, 4, st));
@@ -755,25 +770,29 @@ void msm_run_device(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offset
         HIP_TRY(hipEventRecord(e1, st));
         ctx->prof_events.push_back({e0, e1});
         ctx->prof_launches += 1;
-        ctx->prof_units += M;
-        for (size_t p = 0; p < P; p++) ctx->prof_alg_bytes += (uint64_t)ns[p] * (64 + scalar_kind_bytes(kinds[p]));
+        ctx->prof_units += pl.M;
+        for (size_t p = 0; p < pl.P; p++) ctx->prof_alg_bytes += (uint64_t)ns[p] * (64 + scalar_kind_bytes(kinds[p]));
     }
     // further levels until the fullest bucket is down to one value
-    HIP_TRY(hipEventSynchronize(ctx->msm_event));
-    uint64_t fullest = *(volatile uint32_t*)ctx->msm_pinned;
-    COZK_REQUIRE(fullest <= bound, "msm: histogram larger than the reference count");
+    HIP_TRY(hipEventSynchronize(sw.max_event));
+    uint64_t fullest = *(volatile uint32_t*)sw.max_pinned;
+    COZK_REQUIRE(fullest <= pl.bound, "msm: histogram larger than the reference count");
     uint64_t cnt = (fullest + L0 - 1) / L0;
     uint64_t maxseg = maxseg0;
     g1_xyzz* cur_items = ws.partA.as<g1_xyzz>();
     g1_xyzz* nxt_items = ws.partB.as<g1_xyzz>();
+    // level offsets ping-pong between two buffers of the accumulate workspace (offA belongs to the sort phase)
     uint32_t* cur_off = offA;
-    uint32_t* nxt_off = offB;
+    uint32_t* nxt_off = ws.offB.as<uint32_t>();
+    uint32_t* spare_off = ws.offC.as<uint32_t>();
     while (cnt > 1) {
         uint64_t nseg = maxseg / L1 + nb;
-        scan(true, cur_off, L1, nxt_off, nullptr);
+        msm_scan(st, ws.ptrs.as<uint32_t>(), nb, true, cur_off, L1, nxt_off, nullptr);
         k_msm_accumN<<<cdiv(nseg, TPB), TPB, 0, st>>>(cur_items, cur_off, nxt_off, nb, L1, nxt_items);
         std::swap(cur_items, nxt_items);
-        std::swap(cur_off, nxt_off);
+        uint32_t* done = cur_off;
+        cur_off = nxt_off;
+        nxt_off = (done == offA) ? spare_off : done;
         maxseg = nseg;
         cnt = (cnt + L1 - 1) / L1;
     }
@@ -824,19 +843,65 @@ void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, co
         ws.chunk.reserve((size_t)ngroups * (NB / CH) * sizeof(g1_xyzz));
         ws.grp.reserve((size_t)ngroups * sizeof(g1_xyzz));
         g1_xyzz* dense = ws.bsum.as<g1_xyzz>();
-        size_t s = 0;
-        while (s < kt) {
-            size_t P = 0;
-            uint64_t M = 0;
-            while (s + P < kt && P < maxP) {
-                uint64_t m = (uint64_t)ns[t0 + s + P] * kind_nwin(kinds[t0 + s + P]);
-                if (P > 0 && M + m > (1ull << 28)) break;
-                M += m;
-                P++;
+        // cut the launch sets, then pipeline: sort(k + 1) on the side stream while accumulate(k) runs on the main one
+        struct SetRange { size_t s, P; };
+        std::vector<SetRange> sets;
+        {
+            size_t s = 0;
+            while (s < kt) {
+                size_t P = 0;
+                uint64_t M = 0;
+                while (s + P < kt && P < maxP) {
+                    uint64_t m = (uint64_t)ns[t0 + s + P] * kind_nwin(kinds[t0 + s + P]);
+                    if (P > 0 && M + m > (1ull << 28)) break;
+                    M += m;
+                    P++;
+                }
+                sets.push_back({s, P});
+                s += P;
             }
-            msm_run_device(ctx, bases, offsets + t0 + s, ns + t0 + s, scalars + t0 + s, kinds + t0 + s, P,
-                           dense + (size_t)s * G * NB);
-            s += P;
+        }
+        static const bool pipeline = getenv("COZK_MSM_SERIAL") == nullptr;
+        hipStream_t side = st;
+        if (pipeline && sets.size() > 1) {
+            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            side = ctx->stream2;
+        }
+        for (int b = 0; b < 2; b++) {
+            if (!ws.sort[b].done) HIP_TRY(hipEventCreateWithFlags(&ws.sort[b].done, hipEventDisableTiming));
+            if (!ws.sort[b].consumed) HIP_TRY(hipEventCreateWithFlags(&ws.sort[b].consumed, hipEventDisableTiming));
+        }
+        if (side != st) {
+            // the side stream must see everything the caller enqueued on the main stream (scalars written by kernels,
+            // the previous batch's reads of the sort workspaces)
+            if (!ws.fork) HIP_TRY(hipEventCreateWithFlags(&ws.fork, hipEventDisableTiming));
+            HIP_TRY(hipEventRecord(ws.fork, st));
+            HIP_TRY(hipStreamWaitEvent(side, ws.fork, 0));
+        }
+        std::vector<MsmSetPlan> plans(sets.size());
+        auto launch_sort = [&](size_t i) {
+            const SetRange& r = sets[i];
+            plans[i] = msm_plan(bases, offsets + t0 + r.s, ns + t0 + r.s, kinds + t0 + r.s, r.P);
+            if (plans[i].M == 0) return;
+            MsmSortWs& sw = ws.sort[i & 1];
+            if (i >= 2 && side != st) HIP_TRY(hipStreamWaitEvent(side, sw.consumed, 0));  // its previous user has finished reading it
+            msm_sort(ctx, side, sw, plans[i], bases, offsets + t0 + r.s, ns + t0 + r.s, scalars + t0 + r.s, kinds + t0 + r.s);
+            if (side != st) HIP_TRY(hipEventRecord(sw.done, side));
+        };
+        if (!sets.empty()) launch_sort(0);
+        for (size_t i = 0; i < sets.size(); i++) {
+            if (side != st && i + 1 < sets.size()) launch_sort(i + 1);
+            const SetRange& r = sets[i];
+            g1_xyzz* out_i = dense + (size_t)r.s * G * NB;
+            if (plans[i].M != 0) {
+                MsmSortWs& sw = ws.sort[i & 1];
+                if (side != st) HIP_TRY(hipStreamWaitEvent(st, sw.done, 0));
+                msm_accumulate(ctx, sw, plans[i], bases, ns + t0 + r.s, kinds + t0 + r.s, out_i);
+                if (side != st) HIP_TRY(hipEventRecord(sw.consumed, st));
+            } else {
+                HIP_TRY(hipMemsetAsync(out_i, 0, (size_t)plans[i].nb * sizeof(g1_xyzz), st));  // all buckets = identity (zz = 0)
+            }
+            if (side == st && i + 1 < sets.size()) launch_sort(i + 1);
         }
         k_msm_reduce_chunks<<<cdiv((uint64_t)ngroups * (NB / CH), TPB), TPB, 0, st>>>(dense, ngroups, ws.chunk.as<g1_xyzz>());
         k_msm_reduce_groups<<<ngroups, TPB, 0, st>>>(ws.chunk.as<g1_xyzz>(), ws.grp.as<g1_xyzz>());

@@ -1661,7 +1661,7 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
     bool have_r = false;
     int round = 0;
     for (; round < num_rounds; round++) {
-        if (!no_persist && l->len <= ROUND_PERSIST_MAX && l->len >= 2) break;
+        if (!no_persist && ctx->resident_rounds && l->len <= ROUND_PERSIST_MAX && l->len >= 2) break;
         int rc = cozk_layer_round(ctx, l, e, have_r ? rr : nullptr, pc, coeffs);
         if (rc != COZK_OK) return rc;
         if (cb(user, round, coeffs, rr, nc) != 0) {

@@ -59,6 +59,13 @@ typedef struct cozk_vec cozk_vec;
 int cozk_ctx_create(int device, cozk_ctx** out);
 int cozk_ctx_destroy(cozk_ctx* ctx);
 const char* cozk_last_error(cozk_ctx* ctx);
+/* cozk_layer_prove_rounds keeps one single-workgroup kernel resident for the tail of a layer's sumcheck; while it
+ * waits for the host's challenge, kernels of other streams that the driver mapped to the same hardware queue
+ * cannot start.  That is harmless for independent provers, but provers that need EACH OTHER's round messages to
+ * make progress (several parties of one protocol run driven from one process on one GPU) could then wait for
+ * each other forever (the kernel's 10 s watchdog turns that into an error).  Disable it for such contexts;
+ * one party per process -- the reference's deployment -- is safe.  Default: enabled. */
+int cozk_ctx_set_resident_rounds(cozk_ctx* ctx, int enable);
 int cozk_ctx_synchronize(cozk_ctx* ctx);
 /* raw hipStream_t of the context (so a host can order its own work / events against it) */
 int cozk_ctx_stream(cozk_ctx* ctx, void** out_stream);
