@@ -36,6 +36,8 @@ struct CozkError : std::runtime_error {
     } while (0)
 
 // A growable device scratch buffer (never shrinks; freed with the context).
+// gives the parked blocks of the calling thread's context back to the driver (defined after cozk_ctx)
+static inline void trim_current_pool();
 struct DevBuf {
     void* p = nullptr;
     size_t cap = 0;
@@ -44,7 +46,12 @@ struct DevBuf {
         if (p) HIP_TRY(hipFree(p));
         p = nullptr;
         cap = 0;
-        HIP_TRY(hipMalloc(&p, bytes));
+        if (hipMalloc(&p, bytes) != hipSuccess) {  // the caching allocator may be sitting on the memory we need
+            (void)hipGetLastError();
+            p = nullptr;
+            trim_current_pool();
+            HIP_TRY(hipMalloc(&p, bytes));
+        }
         cap = bytes;
     }
     void release() {
@@ -197,6 +204,9 @@ static inline size_t scalar_kind_bytes(int kind) {
 inline std::mutex g_ctx_mu;
 inline std::unordered_set<cozk_ctx*> g_live_ctx;
 inline thread_local cozk_ctx* t_cur_ctx = nullptr;
+static inline void trim_current_pool() {
+    if (t_cur_ctx) t_cur_ctx->pool.trim();
+}
 static inline bool ctx_is_live(cozk_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     return g_live_ctx.count(ctx) != 0;
