@@ -683,20 +683,33 @@ __global__ void __launch_bounds__(PT) k_spartan_second(const fe* __restrict__ za
 // b, c) on shares, CSR rows (field sums are order-independent, so COO vs CSR order cannot change a bit)
 // Rows up to SPMV_LONG entries: one lane per row.  Longer rows (R1CS has them: the constant-1 column of the
 // transposed matrices that `third_round` walks, worker.rs:241-249, holds an entry of almost every constraint)
-// are queued on the device and reduced by one workgroup each in k_sparse_matvec3_long, so a dense row/column
-// costs a block-wide tree sum instead of a 2^18-step serial loop.
+// are cut into SPMV_CHUNK-entry work items queued on the device: one workgroup reduces one item
+// (k_sparse_matvec3_items), then one workgroup per long row adds up its items' partial sums
+// (k_sparse_matvec3_rows).  A dense column of 2^18 entries costs two short launches instead of a 2^18-step
+// serial loop.  Queue layout in `q`: [0] number of long rows, [1] number of items, then rows[] = (row, first item,
+// item count) and items[] = (row, chunk index).
 static constexpr uint32_t SPMV_LONG = 64;
+static constexpr uint32_t SPMV_CHUNK = 2048;
 template <int NC>
 __global__ void __launch_bounds__(PT) k_sparse_matvec3(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
                                                     const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
                                                     const fe* __restrict__ za, const fe* __restrict__ zb, size_t nrows,
                                                     fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1,
-                                                    uint32_t* __restrict__ long_count, uint32_t* __restrict__ long_rows) {
+                                                    uint32_t* __restrict__ q, uint32_t* __restrict__ q_rows, uint32_t* __restrict__ q_items) {
     size_t r = (size_t)blockIdx.x * PT + threadIdx.x;
     if (r >= nrows) return;
     uint32_t e0 = row_ptr[r], e1 = row_ptr[r + 1];
     if (e1 - e0 > SPMV_LONG) {
-        long_rows[atomicAdd(long_count, 1u)] = (uint32_t)r;
+        uint32_t nchunks = (e1 - e0 + SPMV_CHUNK - 1) / SPMV_CHUNK;
+        uint32_t ri = atomicAdd(&q[0], 1u);
+        uint32_t first = atomicAdd(&q[1], nchunks);
+        q_rows[3 * ri] = (uint32_t)r;
+        q_rows[3 * ri + 1] = first;
+        q_rows[3 * ri + 2] = nchunks;
+        for (uint32_t j = 0; j < nchunks; j++) {
+            q_items[2 * (first + j)] = (uint32_t)r;
+            q_items[2 * (first + j) + 1] = j;
+        }
         return;
     }
     Sh<NC> A, B, C;
@@ -711,30 +724,57 @@ __global__ void __launch_bounds__(PT) k_sparse_matvec3(const uint32_t* __restric
     sh_store<NC>(ob0, ob1, r, B);
     sh_store<NC>(oc0, oc1, r, C);
 }
+// partial[item][3][NC]: the sums of one SPMV_CHUNK-entry slice of a long row
 template <int NC>
-__global__ void __launch_bounds__(PT) k_sparse_matvec3_long(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
-                                                         const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
-                                                         const fe* __restrict__ za, const fe* __restrict__ zb,
-                                                         fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1,
-                                                         const uint32_t* __restrict__ long_count, const uint32_t* __restrict__ long_rows) {
+__global__ void __launch_bounds__(PT) k_sparse_matvec3_items(const uint32_t* __restrict__ row_ptr, const uint32_t* __restrict__ col,
+                                                          const fe* __restrict__ va, const fe* __restrict__ vb, const fe* __restrict__ vc,
+                                                          const fe* __restrict__ za, const fe* __restrict__ zb, const uint32_t* __restrict__ q,
+                                                          const uint32_t* __restrict__ q_items, fe* __restrict__ partial) {
     __shared__ fe sh4[4];
-    uint32_t nlong = *long_count;
-    for (uint32_t q = blockIdx.x; q < nlong; q += gridDim.x) {  // every workgroup reaches the end of the queue
-        uint32_t r = long_rows[q];
+    uint32_t nitems = q[1];
+    for (uint32_t it = blockIdx.x; it < nitems; it += gridDim.x) {  // every workgroup reaches the end of the queue
+        uint32_t r = q_items[2 * it], j = q_items[2 * it + 1];
+        uint32_t lo = row_ptr[r] + j * SPMV_CHUNK;
+        uint32_t hi = min(lo + SPMV_CHUNK, row_ptr[r + 1]);
         Sh<NC> A, B, C;
         for (int k = 0; k < NC; k++) A.c[k] = B.c[k] = C.c[k] = Fr::zero();
-        for (uint32_t e = row_ptr[r] + threadIdx.x; e < row_ptr[r + 1]; e += PT) {
+        for (uint32_t e = lo + threadIdx.x; e < hi; e += PT) {
             Sh<NC> z = sh_load<NC>(za, zb, col[e]);
             A = sh_add<NC>(A, sh_mul_public<NC>(z, fe_load(va + e)));
             B = sh_add<NC>(B, sh_mul_public<NC>(z, fe_load(vb + e)));
             C = sh_add<NC>(C, sh_mul_public<NC>(z, fe_load(vc + e)));
         }
+        fe* out = partial + (size_t)it * 3 * NC;
         for (int k = 0; k < NC; k++) {
-            A.c[k] = fr_block_sum(A.c[k], sh4);
-            B.c[k] = fr_block_sum(B.c[k], sh4);
-            C.c[k] = fr_block_sum(C.c[k], sh4);
+            fe a = fr_block_sum(A.c[k], sh4), b = fr_block_sum(B.c[k], sh4), c = fr_block_sum(C.c[k], sh4);
+            if (threadIdx.x == 0) {
+                fe_store(out + k, a);
+                fe_store(out + NC + k, b);
+                fe_store(out + 2 * NC + k, c);
+            }
         }
+    }
+}
+template <int NC>
+__global__ void __launch_bounds__(PT) k_sparse_matvec3_rows(const uint32_t* __restrict__ q, const uint32_t* __restrict__ q_rows,
+                                                         const fe* __restrict__ partial, fe* oa0, fe* oa1, fe* ob0, fe* ob1, fe* oc0, fe* oc1) {
+    __shared__ fe sh4[4];
+    uint32_t nlong = q[0];
+    for (uint32_t ri = blockIdx.x; ri < nlong; ri += gridDim.x) {
+        uint32_t r = q_rows[3 * ri], first = q_rows[3 * ri + 1], n = q_rows[3 * ri + 2];
+        fe acc[3 * NC];
+        for (int k = 0; k < 3 * NC; k++) acc[k] = Fr::zero();
+        for (uint32_t j = threadIdx.x; j < n; j += PT)
+            for (int k = 0; k < 3 * NC; k++) acc[k] = Fr::add(acc[k], fe_load(partial + (size_t)(first + j) * 3 * NC + k));
+        fe tot[3 * NC];
+        for (int k = 0; k < 3 * NC; k++) tot[k] = fr_block_sum(acc[k], sh4);
         if (threadIdx.x == 0) {
+            Sh<NC> A, B, C;
+            for (int k = 0; k < NC; k++) {
+                A.c[k] = tot[k];
+                B.c[k] = tot[NC + k];
+                C.c[k] = tot[2 * NC + k];
+            }
             sh_store<NC>(oa0, oa1, r, A);
             sh_store<NC>(ob0, ob1, r, B);
             sh_store<NC>(oc0, oc1, r, C);
@@ -1307,25 +1347,32 @@ int cozk_sparse_matvec3(cozk_ctx* ctx, const cozk_vec* row_ptr, const cozk_vec* 
             o[i]->a0 = dev_alloc_fe(nrows);
             o[i]->b0 = z->mode == COZK_MODE_REP3 ? dev_alloc_fe(nrows) : nullptr;
         }
-        // device-side queue of the rows longer than SPMV_LONG (count + indices) in the context scratch
-        ctx->scratch.reserve((nrows + 16) * sizeof(uint32_t));
-        uint32_t* lcount = ctx->scratch.as<uint32_t>();
-        uint32_t* lrows = lcount + 16;
-        HIP_TRY(hipMemsetAsync(lcount, 0, sizeof(uint32_t), ctx->stream));
+        // device-side queues of the long rows and of their SPMV_CHUNK-entry work items, and the items' partial sums
+        const size_t nnz = col->n;
+        const size_t max_rows = nnz / SPMV_LONG + 1, max_items = nnz / SPMV_CHUNK + max_rows;
+        const int nc = z->mode == COZK_MODE_REP3 ? 2 : 1;
+        const size_t q_words = 16 + 3 * max_rows + 2 * max_items;
+        const size_t q_bytes = (q_words * sizeof(uint32_t) + 63) & ~(size_t)63;
+        ctx->scratch.reserve(q_bytes + max_items * 3 * nc * sizeof(fe));
+        uint32_t* q = ctx->scratch.as<uint32_t>();
+        uint32_t* q_rows = q + 16;
+        uint32_t* q_items = q_rows + 3 * max_rows;
+        fe* partial = reinterpret_cast<fe*>(reinterpret_cast<char*>(ctx->scratch.p) + q_bytes);
+        HIP_TRY(hipMemsetAsync(q, 0, 2 * sizeof(uint32_t), ctx->stream));
         const uint32_t* rp = (const uint32_t*)row_ptr->d;
         const uint32_t* ci = (const uint32_t*)col->d;
         const fe *pa = (const fe*)val_a->d, *pb = (const fe*)val_b->d, *pc = (const fe*)val_c->d;
-        unsigned glong = (unsigned)std::min<size_t>(nrows, 1024);
+        unsigned g_items = (unsigned)std::min<size_t>(max_items, 4096), g_rows = (unsigned)std::min<size_t>(max_rows, 1024);
         if (z->mode == COZK_MODE_REP3) {
             k_sparse_matvec3<2><<<grid_for(nrows), PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), poly_b(z), nrows, o[0]->a0, o[0]->b0, o[1]->a0,
-                                                                        o[1]->b0, o[2]->a0, o[2]->b0, lcount, lrows);
-            k_sparse_matvec3_long<2><<<glong, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), poly_b(z), o[0]->a0, o[0]->b0, o[1]->a0, o[1]->b0, o[2]->a0,
-                                                                   o[2]->b0, lcount, lrows);
+                                                                        o[1]->b0, o[2]->a0, o[2]->b0, q, q_rows, q_items);
+            k_sparse_matvec3_items<2><<<g_items, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), poly_b(z), q, q_items, partial);
+            k_sparse_matvec3_rows<2><<<g_rows, PT, 0, ctx->stream>>>(q, q_rows, partial, o[0]->a0, o[0]->b0, o[1]->a0, o[1]->b0, o[2]->a0, o[2]->b0);
         } else {
             k_sparse_matvec3<1><<<grid_for(nrows), PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), nullptr, nrows, o[0]->a0, nullptr, o[1]->a0, nullptr,
-                                                                        o[2]->a0, nullptr, lcount, lrows);
-            k_sparse_matvec3_long<1><<<glong, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), nullptr, o[0]->a0, nullptr, o[1]->a0, nullptr, o[2]->a0, nullptr,
-                                                                   lcount, lrows);
+                                                                        o[2]->a0, nullptr, q, q_rows, q_items);
+            k_sparse_matvec3_items<1><<<g_items, PT, 0, ctx->stream>>>(rp, ci, pa, pb, pc, poly_a(z), nullptr, q, q_items, partial);
+            k_sparse_matvec3_rows<1><<<g_rows, PT, 0, ctx->stream>>>(q, q_rows, partial, o[0]->a0, nullptr, o[1]->a0, nullptr, o[2]->a0, nullptr);
         }
         HIP_TRY(hipGetLastError());
         *out_za = o[0];
