@@ -157,14 +157,14 @@ def main():
     peak_gmul = lanes * 2000 / mm_ms / 1e6
     sat_ms = min(ctx.bench_montmul(lanes, 2000, 1) for _ in range(3))
     ctx.close()
-    # one mixed XYZZ addition in the gather kernel = 10 limb products + 9 Montgomery reductions of 81 mads each
-    # (Y3's two products share a reduction) = 1539 mads = 9.5 stand-alone products of 162 mads, which is what the
-    # peak counts
-    MULS_PER_MADD = 1539.0 / 162.0
+    # one mixed XYZZ addition in the gather kernel = 8 limb products (81 mads) + 2 squarings (45) + 9 Montgomery
+    # reductions (81; Y3's two products share one) = 1467 mads = 9.06 stand-alone products of 162 mads, which is
+    # what the peak counts
+    MULS_PER_MADD = 1467.0 / 162.0
     gmul = prof["point_adds"] * MULS_PER_MADD / (prof["total_ms"] * 1e-3) / 1e9 if prof["total_ms"] > 0 else 0.0
     roofline["int_alu"] = {"achieved": round(gmul, 2), "peak": round(peak_gmul, 2), "unit": "G Fq-montmul/s",
                            "frac": round(gmul / peak_gmul, 4), "saturated_8x32_peak": round(lanes * 2000 / sat_ms / 1e6, 2),
-                           "note": "mixed XYZZ addition = 9.5 products of the 9x29-bit multiplier (10 limb products + 9 reductions); peak = that multiplier's dependent-product micro-benchmark, measured in this run"}
+                           "note": "mixed XYZZ addition = 9.06 products of the 9x29-bit multiplier (8 products + 2 squarings + 9 reductions = 1467 mads); peak = that multiplier's dependent-product micro-benchmark, measured in this run"}
 
     out = {"metric": "RISC-V cycles proved/sec (co-Jolt hot path: PST13 commit + dense GKR grand product + openings)",
            "value": round(value, 1), "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

@@ -91,6 +91,38 @@ static __device__ __forceinline__ f9 f9_mul(const f9& a, const f9& b) {
     r.l[8] = (uint32_t)acc;
     return r;
 }
+// a * a / R' mod p for a normalised a: the 36 off-diagonal products are taken once against the doubled operand
+// (limbs < 2^30, products < 2^59, at most 4 of them + one square + 9 m*p terms per column: < 2^62)
+static __device__ __forceinline__ f9 f9_sqr(const f9& a) {
+    uint64_t acc = 0;
+    uint32_t m[9], d[9];
+    f9 r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a.l[i] * d[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F9_P[k - i];
+        m[k] = ((uint32_t)acc * F9_INV) & F9_MASK;
+        acc += (uint64_t)m[k] * F9_P[0];
+        acc >>= 29;
+    }
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+#pragma unroll
+        for (int i = k - 8; 2 * i < k; i++) acc += (uint64_t)a.l[i] * d[k - i];
+        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F9_P[k - i];
+        r.l[k - 9] = (uint32_t)acc & F9_MASK;
+        acc >>= 29;
+    }
+    r.l[8] = (uint32_t)acc;
+    return r;
+}
 // (a * b + c * d) / R' mod p under one reduction
 static __device__ __forceinline__ f9 f9_mul_add2(const f9& a, const f9& b, const f9& c, const f9& d) {
     uint64_t acc = 0;
@@ -145,6 +177,8 @@ static __device__ __forceinline__ f9 f9_sub(const f9& a, const uint32_t (&C)[9],
 }
 // value == 0 mod p for a product output (normalised, < 2p): all limbs 0, or equal to p
 static __device__ __forceinline__ bool f9_is_zero_mod_p(const f9& a) {
+    // almost always decided by the lowest limb (it is 0 or p's lowest limb for one value in 2^28)
+    if (a.l[0] != 0u && a.l[0] != F9_P[0]) return false;
     uint32_t z = 0, e = 0;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
@@ -181,9 +215,9 @@ static __device__ __forceinline__ bool madd9(xyzz9& acc, const f9& qx, const f9&
     f9 S2 = f9_mul(qy, acc.zzz);
     f9 Pd = f9_norm(f9_sub(U2, F9_C7, acc.x));
     f9 Rd = f9_norm(f9_sub(S2, F9_C3, acc.y));
-    f9 PP = f9_mul(Pd, Pd);
+    f9 PP = f9_sqr(Pd);
     if (f9_is_zero_mod_p(PP)) return false;
-    f9 RR = f9_mul(Rd, Rd);
+    f9 RR = f9_sqr(Rd);
     f9 PPP = f9_mul(Pd, PP);
     f9 Q = f9_mul(acc.x, PP);
     f9 X3;
