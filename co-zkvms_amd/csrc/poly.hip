@@ -1613,8 +1613,7 @@ int cozk_layer_compute_cubic(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
 int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64_t* r, const uint64_t prev_claim[4],
                      uint64_t out_coeffs[16]) {
     if (!ctx || !l || !e || !prev_claim || !out_coeffs) return COZK_ERR_INVALID_ARG;
-    static const size_t small_max = getenv("COZK_ROUND_SMALL") ? (size_t)atol(getenv("COZK_ROUND_SMALL")) : ROUND_SMALL_MAX;
-    if (l->len > small_max) {
+    if (l->len > ROUND_SMALL_MAX) {
         if (r) {
             int rc = cozk_layer_bind(ctx, l, r);
             if (rc != COZK_OK) return rc;
