@@ -4,7 +4,9 @@
 // COUNT.  With saturated 8 x 32-bit limbs every multiply-add needs a second instruction to catch the carry out of
 // the 64-bit accumulator (136 mads + 136 addc + moves ~ 330 instructions, 129 G products/s measured).  With 29-bit
 // limbs the 18 products of a column (9 of a*b, 9 of m*p, each < 2^58) fit a 64-bit accumulator with room to
-// spare, so the carry instructions disappear: 162 mads + ~60 shifts/masks, 175 G products/s measured.
+// spare, so the carry instructions disappear: 162 mads + ~45 shifts/masks.  Written as plain C++ the compiler
+// splits each column into two accumulator chains and merges them with a 64-bit add (170 G products/s); the
+// fused single-accumulator chains of fq9_mac.inc avoid that (177 G products/s, gather kernel -3.8 %).
 //
 // Radix R' = 2^261 leaves 7 spare bits above p (p / R' < 1/169), which the mixed addition uses twice:
 //   * VALUES are never reduced: a product of inputs < A p and < B p is < p (1 + A B / 169).  The invariant kept
@@ -22,6 +24,8 @@
 #pragma once
 #include "ec.cuh"
 #include "fq9_consts.inc"
+#include "fq9_mac.inc"
+#include "fq9_mul.inc"
 
 struct f9 {
     uint32_t l[9];
@@ -65,62 +69,22 @@ static __device__ __forceinline__ f9 f9_const(const uint32_t (&c)[9]) {
 // a * b / R' mod p, output limbs normalised.  Column sums: 9 a*b + 9 m*p products; callers keep
 // 9 * max(a_i) * max(b_i) + 9 * 2^58 below 2^64 (limb bounds stated at each call site).
 static __device__ __forceinline__ f9 f9_mul(const f9& a, const f9& b) {
+    // fused single-accumulator chains (fq9_mac.inc / fq9_mul.inc): 162 mads + 9 m computations + 17 shifts + 17 masks
     uint64_t acc = 0;
     uint32_t m[9];
     f9 r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) acc += (uint64_t)a.l[i] * b.l[k - i];
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F9_P[k - i];
-        m[k] = ((uint32_t)acc * F9_INV) & F9_MASK;
-        acc += (uint64_t)m[k] * F9_P[0];
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)m[i] * F9_P[k - i];
-        }
-        r.l[k - 9] = (uint32_t)acc & F9_MASK;
-        acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
+    F9_MUL_BODY
     return r;
 }
 // a * a / R' mod p for a normalised a: the 36 off-diagonal products are taken once against the doubled operand
 // (limbs < 2^30, products < 2^59, at most 4 of them + one square + 9 m*p terms per column: < 2^62)
 static __device__ __forceinline__ f9 f9_sqr(const f9& a) {
     uint64_t acc = 0;
-    uint32_t m[9], d[9];
+    uint32_t m[9], dd[9];
     f9 r;
 #pragma unroll
-    for (int i = 0; i < 9; i++) d[i] = a.l[i] << 1;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)a.l[i] * d[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F9_P[k - i];
-        m[k] = ((uint32_t)acc * F9_INV) & F9_MASK;
-        acc += (uint64_t)m[k] * F9_P[0];
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; 2 * i < k; i++) acc += (uint64_t)a.l[i] * d[k - i];
-        if ((k & 1) == 0) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * F9_P[k - i];
-        r.l[k - 9] = (uint32_t)acc & F9_MASK;
-        acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
+    for (int i = 0; i < 9; i++) dd[i] = a.l[i] << 1;
+    F9_SQR_BODY
     return r;
 }
 // (a * b + c * d) / R' mod p under one reduction
@@ -128,31 +92,7 @@ static __device__ __forceinline__ f9 f9_mul_add2(const f9& a, const f9& b, const
     uint64_t acc = 0;
     uint32_t m[9];
     f9 r;
-#pragma unroll
-    for (int k = 0; k < 9; k++) {
-#pragma unroll
-        for (int i = 0; i <= k; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
-        }
-#pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * F9_P[k - i];
-        m[k] = ((uint32_t)acc * F9_INV) & F9_MASK;
-        acc += (uint64_t)m[k] * F9_P[0];
-        acc >>= 29;
-    }
-#pragma unroll
-    for (int k = 9; k < 17; k++) {
-#pragma unroll
-        for (int i = k - 8; i < 9; i++) {
-            acc += (uint64_t)a.l[i] * b.l[k - i];
-            acc += (uint64_t)c.l[i] * d.l[k - i];
-            acc += (uint64_t)m[i] * F9_P[k - i];
-        }
-        r.l[k - 9] = (uint32_t)acc & F9_MASK;
-        acc >>= 29;
-    }
-    r.l[8] = (uint32_t)acc;
+    F9_MUL_ADD2_BODY
     return r;
 }
 // carry propagation: limbs < 2^32 - 8 in, limbs 0..7 < 2^29 out (the top limb keeps the rest)
