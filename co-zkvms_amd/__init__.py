@@ -9,6 +9,6 @@ from .engine import (Context, Vec, Bases, FR_MOD, FQ_MOD, fr_to_mont_limbs, mont
                      point_to_abi, point_from_abi)
 from .poly import (Rep3DensePolynomial, Rep3DenseInterleavedPolynomial, SplitEqPolynomial, eq_evals,
                    open_quadratic_evals, pst_fold, prod_sumcheck_evals, spartan_first_round, spartan_second_round,
-                   sparse_matvec3)
+                   sparse_matvec3, fingerprint_leaves)
 from .harness import Harness, HarnessConfig, HarnessResult
 from .spartan import SpartanHarness, SpartanConfig, SpartanResult

@@ -105,6 +105,7 @@ SIGNATURES = {
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_ctx_set_resident_rounds": (_i, [_vp, _i]),
     "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
+    "cozk_fingerprint_leaves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _sz, _sz]),
     "cozk_layer_prove_rounds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cozk_layer_final_claims": (_i, [_vp, _vp, _vp]),
     "cozk_layer_output_local": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _pp]),

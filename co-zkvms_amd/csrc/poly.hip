@@ -134,6 +134,53 @@ __global__ void __launch_bounds__(PT) k_poly_lincomb(const fe* const* __restrict
     sh_store<NC>(oa, ob, i, acc);
 }
 
+// K11 leaf fingerprints (compute_leaves of the three memory-checking instances, e.g.
+// co-jolt/src/jolt/vm/bytecode/worker.rs:57-100, read_write_memory/worker.rs:207-260):
+//   leaf[i] = sum_k c_k * col_k[i]  (compact public columns, CompactPolynomial::field_mul)
+//           + sum_j d_j * poly_j[i]  (shared or plain Fr polynomials, mul_public)
+//           + constant               (e.g. -tau, or gamma^7 - tau for the write leaves)
+// The public part enters a Rep3 leaf through add_public: party 0's a, party 1's b.  `cs` holds c_k * R (the
+// Montgomery form of the Montgomery form), so that one product with the plain small integer gives c_k * v in
+// Montgomery form.
+struct SmallCol {
+    const void* p;
+    int kind;
+};
+static __device__ __forceinline__ uint64_t small_load(const SmallCol& c, size_t i) {
+    switch (c.kind) {
+        case COZK_SCALAR_U8: return reinterpret_cast<const uint8_t*>(c.p)[i];
+        case COZK_SCALAR_U16: return reinterpret_cast<const uint16_t*>(c.p)[i];
+        case COZK_SCALAR_U32: return reinterpret_cast<const uint32_t*>(c.p)[i];
+        default: return reinterpret_cast<const uint64_t*>(c.p)[i];
+    }
+}
+template <int NC>
+__global__ void __launch_bounds__(PT) k_fingerprint_leaves(const SmallCol* __restrict__ cols, const fe* __restrict__ cs, int ks,
+                                                        const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
+                                                        const fe* __restrict__ ds, int kp, fe constant, int pub_a, int pub_b, fe* oa, fe* ob,
+                                                        size_t n) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    fe pub = constant;
+    for (int k = 0; k < ks; k++) {
+        uint64_t v = small_load(cols[k], i);
+        fe x = Fr::zero();
+        x.l[0] = (uint32_t)v;
+        x.l[1] = (uint32_t)(v >> 32);
+        pub = Fr::add(pub, Fr::mul(fe_load(cs + k), x));
+    }
+    Sh<NC> acc;
+    for (int c = 0; c < NC; c++) acc.c[c] = Fr::zero();
+    for (int j = 0; j < kp; j++) {
+        fe d = fe_load(ds + j);
+        if (pa[j]) acc.c[0] = Fr::add(acc.c[0], Fr::mul(fe_load(pa[j] + i), d));
+        if (NC == 2 && pb[j]) acc.c[NC - 1] = Fr::add(acc.c[NC - 1], Fr::mul(fe_load(pb[j] + i), d));
+    }
+    if (pub_a) acc.c[0] = Fr::add(acc.c[0], pub);
+    if (NC == 2 && pub_b) acc.c[NC - 1] = Fr::add(acc.c[NC - 1], pub);
+    sh_store<NC>(oa, ob, i, acc);
+}
+
 // quadratic opening-reduction round (compute_quadratic, opening_proof.rs:374-414): per opening
 // eval_0 = sum_i poly[i]*eq[i], eval_2 = sum_i (2 poly[i+h] - poly[i]) * (2 eq[i+h] - eq[i]);
 // partial[(2*y + e) * gridDim.x + x]; the (a+b)*TWO_INV conversion is folded into the finisher.
@@ -1170,6 +1217,72 @@ int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, c
         else k_poly_lincomb<1><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
         HIP_TRY(hipGetLastError());
         *out = o;
+    });
+}
+
+// compute_leaves (K11): see k_fingerprint_leaves.  Writes n leaves at out_a/out_b[offset ..]; public polynomials
+// (MODE_PLAIN) among `polys` count as part of the public term when the output is REP3.
+int cozk_fingerprint_leaves(cozk_ctx* ctx, const cozk_vec* const* cols, const uint64_t* col_coeffs, size_t ks, const cozk_poly* const* polys,
+                            const uint64_t* poly_coeffs, size_t kp, const uint64_t constant[4], int mode, int party_id, cozk_vec* out_a,
+                            cozk_vec* out_b, size_t offset, size_t n) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && constant && out_a && out_a->kind == COZK_SCALAR_FR && (mode == COZK_MODE_PLAIN || mode == COZK_MODE_REP3) &&
+                         party_id >= 0 && party_id < 3 && n > 0 && offset + n <= out_a->n && (ks == 0 || (cols && col_coeffs)) &&
+                         (kp == 0 || (polys && poly_coeffs)) && ks <= 32 && kp <= 32,
+                     "fingerprint_leaves: bad argument");
+        COZK_REQUIRE(mode == COZK_MODE_PLAIN || (out_b && out_b->kind == COZK_SCALAR_FR && out_b->n == out_a->n), "fingerprint_leaves: share b output missing");
+        std::vector<SmallCol> hcols(ks);
+        std::vector<fe> hcs(ks), hds(kp);
+        std::vector<const fe*> ha(kp), hb(kp);
+        for (size_t k = 0; k < ks; k++) {
+            const cozk_vec* v = cols[k];
+            COZK_REQUIRE(v && v->n >= n && (v->kind == COZK_SCALAR_U8 || v->kind == COZK_SCALAR_U16 || v->kind == COZK_SCALAR_U32 || v->kind == COZK_SCALAR_U64),
+                         "fingerprint_leaves: compact columns are U8 / U16 / U32 / U64 vectors of >= n entries");
+            hcols[k] = SmallCol{v->d, v->kind};
+            hcs[k] = Fr::to_mont(fe_from_u64x4(col_coeffs + 4 * k));  // c * R^2: one product with a plain integer -> Montgomery c * v
+        }
+        for (size_t j = 0; j < kp; j++) {
+            const cozk_poly* p = polys[j];
+            COZK_REQUIRE(p && p->len >= n, "fingerprint_leaves: polynomial shorter than n");
+            hds[j] = fe_from_u64x4(poly_coeffs + 4 * j);
+            if (p->mode == COZK_MODE_REP3) {
+                COZK_REQUIRE(mode == COZK_MODE_REP3, "fingerprint_leaves: shared input needs a shared output");
+                ha[j] = poly_a(p);
+                hb[j] = poly_b(p);
+            } else if (mode == COZK_MODE_REP3) {
+                ha[j] = party_id == 0 ? poly_a(p) : nullptr;  // add_public: P0's a, P1's b
+                hb[j] = party_id == 1 ? poly_a(p) : nullptr;
+            } else {
+                ha[j] = poly_a(p);
+                hb[j] = nullptr;
+            }
+        }
+        size_t meta = ks * sizeof(SmallCol) + 64 + (ks + kp) * sizeof(fe) + 64 + 2 * kp * sizeof(void*) + 64;
+        ctx->scratch.reserve(meta);
+        char* base = (char*)ctx->scratch.p;
+        SmallCol* dcols = (SmallCol*)base;
+        fe* dcs = (fe*)(((uintptr_t)(dcols + ks) + 31) & ~(uintptr_t)31);
+        fe* dds = dcs + ks;
+        const fe** da = (const fe**)(((uintptr_t)(dds + kp) + 15) & ~(uintptr_t)15);
+        const fe** db = da + kp;
+        if (ks) {
+            HIP_TRY(hipMemcpyAsync(dcols, hcols.data(), ks * sizeof(SmallCol), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(dcs, hcs.data(), ks * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+        }
+        if (kp) {
+            HIP_TRY(hipMemcpyAsync(dds, hds.data(), kp * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(da, ha.data(), kp * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(db, hb.data(), kp * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+        }
+        HIP_TRY(hipStreamSynchronize(ctx->stream));  // the staging vectors live on this stack frame
+        fe cst = fe_from_u64x4(constant);
+        fe* oa = (fe*)out_a->d + offset;
+        if (mode == COZK_MODE_REP3)
+            k_fingerprint_leaves<2><<<grid_for(n), PT, 0, ctx->stream>>>(dcols, dcs, (int)ks, da, db, dds, (int)kp, cst, party_id == 0, party_id == 1, oa,
+                                                                        (fe*)out_b->d + offset, n);
+        else
+            k_fingerprint_leaves<1><<<grid_for(n), PT, 0, ctx->stream>>>(dcols, dcs, (int)ks, da, db, dds, (int)kp, cst, 1, 0, oa, nullptr, n);
+        HIP_TRY(hipGetLastError());
     });
 }
 

@@ -179,6 +179,18 @@ def open_quadratic_evals(polys, eqs):
     return [(v[2 * i], v[2 * i + 1]) for i in range(k)]
 
 
+def fingerprint_leaves(ctx, cols, col_coeffs, polys, poly_coeffs, constant, mode, party_id, out_a, out_b=None, offset=0, n=None):
+    """compute_leaves (K11): leaf = sum c_k col_k + sum d_j poly_j + constant into out_a/out_b[offset ..]"""
+    if n is None:
+        n = min([len(c) for c in cols] + [len(p) for p in polys])
+    cc = fr_to_mont_limbs(list(col_coeffs)) if cols else np.zeros((1, 4), dtype=np.uint64)
+    pc = fr_to_mont_limbs(list(poly_coeffs)) if polys else np.zeros((1, 4), dtype=np.uint64)
+    ca = (ctypes.c_void_p * max(1, len(cols)))(*[c.h for c in cols])
+    ctx.check(ctx._l.cozk_fingerprint_leaves(ctx.h, ca, cc.ctypes.data, len(cols), _ptr_array(polys) if polys else None, pc.ctypes.data, len(polys),
+                                             _fr(constant).ctypes.data, L.MODE_REP3 if mode == "rep3" else L.MODE_PLAIN, party_id, out_a.h,
+                                             out_b.h if out_b is not None else None, offset, n))
+
+
 def pst_fold(ctx, r_vec, p, q_vec, r_next):
     pp = _fr(p)
     ctx.check(ctx._l.cozk_pst_fold(ctx.h, r_vec.h, pp.ctypes.data, q_vec.h, r_next.h))

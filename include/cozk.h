@@ -177,6 +177,16 @@ int cozk_poly_dot_product_with_public(cozk_ctx* ctx, const cozk_poly* p, const c
  * REP3 combination are public polynomials added via add_public for `party_id` */
 int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, const uint64_t* coeffs,
                                  size_t k, int out_mode, int party_id, cozk_poly** out);
+/* compute_leaves of the memory-checking instances (K11; co-jolt/src/jolt/vm/bytecode/worker.rs:57-100,
+ * read_write_memory/worker.rs:207-300): leaf[i] = sum_k col_coeffs[k] * cols[k][i] (compact public columns: U8 /
+ * U16 / U32 / U64 vectors, CompactPolynomial::field_mul) + sum_j poly_coeffs[j] * polys[j][i] (shared or public
+ * Fr polynomials, mul_public) + constant (e.g. -tau).  In MODE_REP3 the public part enters through add_public
+ * (party 0's a, party 1's b).  Writes n leaves at out_a / out_b[offset ..] (out_b NULL for MODE_PLAIN), so the leaves
+ * of a batch land in one buffer that cozk_layer_create adopts. */
+int cozk_fingerprint_leaves(cozk_ctx* ctx, const cozk_vec* const* cols, const uint64_t* col_coeffs, size_t n_cols,
+                            const cozk_poly* const* polys, const uint64_t* poly_coeffs, size_t n_polys,
+                            const uint64_t constant[4], int mode, int party_id, cozk_vec* out_a, cozk_vec* out_b,
+                            size_t offset, size_t n);
 /* compute_quadratic inner sums for the live openings of one round (opening_proof.rs:374-414):
  * out[2i] = eval_0, out[2i+1] = eval_2 (additive) */
 int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys,

@@ -999,3 +999,33 @@ def sparse_matvec(entries, z, nrows):
     for row, col, val in entries:
         out[row] = sh_add(out[row], sh_mul_public(z[col], val))
     return out
+
+
+# --------------------------------------------------------------------------------------------
+# K11: memory-checking leaf fingerprints
+# --------------------------------------------------------------------------------------------
+def fingerprint_leaves(cols, col_coeffs, polys, poly_coeffs, constant, party=None):
+    """compute_leaves (co-jolt/src/jolt/vm/bytecode/worker.rs:57-100, read_write_memory/worker.rs:207-300):
+    leaf[i] = sum_k c_k * cols[k][i] + sum_j d_j * polys[j][i] + constant.  cols: lists of small integers (compact
+    public columns); polys: lists of ints (public) or (a, b) tuples (Rep3 shares); party None = plain prover,
+    otherwise the public part enters through add_public (party 0: a, party 1: b; rep3::arithmetic::add_public)."""
+    n = min([len(c) for c in cols] + [len(p) for p in polys])
+    out = []
+    for i in range(n):
+        pub = constant % R
+        for c, col in zip(col_coeffs, cols):
+            pub = (pub + c * col[i]) % R
+        sa = sb = 0
+        for d, p in zip(poly_coeffs, polys):
+            v = p[i]
+            if isinstance(v, tuple):
+                sa = (sa + d * v[0]) % R
+                sb = (sb + d * v[1]) % R
+            else:
+                pub = (pub + d * v) % R
+        if party is None:
+            assert sb == 0
+            out.append((sa + pub) % R)
+        else:
+            out.append(((sa + (pub if party == 0 else 0)) % R, (sb + (pub if party == 1 else 0)) % R))
+    return out

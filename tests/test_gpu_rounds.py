@@ -97,3 +97,57 @@ def test_spartan_zero_round_sparse_matvec(cozk, ctx, mode):
     assert za.coeffs() == O.sparse_matvec(ea, z, nrows)
     assert zb.coeffs() == O.sparse_matvec(eb, z, nrows)
     assert zc.coeffs() == O.sparse_matvec(ec, z, nrows)
+
+
+@pytest.mark.parametrize("party", [None, 0, 1, 2])
+def test_fingerprint_leaves_k11(cozk, ctx, party):
+    """compute_leaves (K11): bytecode-shaped fingerprint gamma a + gamma^2 v0 + ... + shared term - tau over compact
+    u8 / u16 / u32 / u64 columns, one shared and one public Fr polynomial; read leaves at offset 0, write leaves
+    (+ gamma^7) right behind them in the same buffer, as the batch of two circuits is laid out"""
+    rng = O.SplitMix64(900 + (party or 0) * 3 + (party is None))
+    n = 300  # not a multiple of the block size
+    mode = "plain" if party is None else "rep3"
+    kinds = [cozk.SCALAR_U8, cozk.SCALAR_U16, cozk.SCALAR_U32, cozk.SCALAR_U64]
+    bits = {cozk.SCALAR_U8: 8, cozk.SCALAR_U16: 16, cozk.SCALAR_U32: 32, cozk.SCALAR_U64: 64}
+    cols_ref = [[rng.next() & ((1 << bits[k]) - 1) for _ in range(n)] for k in kinds]
+    cols_ref[3][0] = (1 << 64) - 1
+    cols = [cozk.Vec.from_ints(ctx, c, kind=k) for c, k in zip(cols_ref, kinds)]
+    gamma, tau = rng.field(), rng.field()
+    g = [pow(gamma, e, O.R) for e in range(1, 8)]
+    shared = _sh(rng, n, mode)
+    public = [rng.field() for _ in range(n)]
+    polys_ref = [shared, public]
+    polys = [cozk.Rep3DensePolynomial.new(ctx, shared), cozk.Rep3DensePolynomial.new(ctx, public)]
+    out_a = cozk.Vec.alloc(ctx, 2 * n)
+    out_b = cozk.Vec.alloc(ctx, 2 * n) if mode == "rep3" else None
+    pid = party or 0
+    cozk.fingerprint_leaves(ctx, cols, g[:4], polys, [g[4], g[5]], (-tau) % O.R, mode, pid, out_a, out_b, offset=0, n=n)
+    cozk.fingerprint_leaves(ctx, cols, g[:4], polys, [g[4], g[5]], (g[6] - tau) % O.R, mode, pid, out_a, out_b, offset=n, n=n)
+    read = O.fingerprint_leaves(cols_ref, g[:4], polys_ref, [g[4], g[5]], (-tau) % O.R, party)
+    write = O.fingerprint_leaves(cols_ref, g[:4], polys_ref, [g[4], g[5]], (g[6] - tau) % O.R, party)
+    a = out_a.to_ints()
+    if mode == "rep3":
+        b = out_b.to_ints()
+        assert list(zip(a, b)) == read + write
+    else:
+        assert a == read + write
+
+
+def test_fingerprint_leaves_parties_reconstruct_plain(cozk, ctx):
+    """the three parties' Rep3 leaves open to the plain prover's leaves (public part added exactly once)"""
+    rng = O.SplitMix64(911)
+    n = 64
+    col = [rng.next() & 0xffff for _ in range(n)]
+    v = [rng.field() for _ in range(n)]
+    t0, t1 = [rng.field() for _ in range(n)], [rng.field() for _ in range(n)]
+    t2 = [(x - y - z) % O.R for x, y, z in zip(v, t0, t1)]
+    shares = [list(zip(t0, t2)), list(zip(t1, t0)), list(zip(t2, t1))]
+    gamma, tau = rng.field(), rng.field()
+    plain = O.fingerprint_leaves([col], [gamma], [v], [gamma * gamma % O.R], (-tau) % O.R, None)
+    a_sum = [0] * n
+    for p in range(3):
+        out_a, out_b = cozk.Vec.alloc(ctx, n), cozk.Vec.alloc(ctx, n)
+        cozk.fingerprint_leaves(ctx, [cozk.Vec.from_ints(ctx, col, kind=cozk.SCALAR_U16)], [gamma], [cozk.Rep3DensePolynomial.new(ctx, shares[p])],
+                                [gamma * gamma % O.R], (-tau) % O.R, "rep3", p, out_a, out_b)
+        a_sum = [(x + y) % O.R for x, y in zip(a_sum, out_a.to_ints())]
+    assert a_sum == plain
