@@ -131,3 +131,22 @@ def test_msm_linearity_large(cozk, ctx):
     pa, pb, pc = B.batch_msm([a, b, c])
     assert ctx.g1_sum([pa, pb]) == pc
     assert O.g1_is_on_curve(pc) and pc is not None
+
+
+def test_msm_repeated_bases_take_the_exception_path(cozk, ctx):
+    """every base is the same point, so inside a bucket every addition after the first is P + P or P - P: the
+    9x29 gather kernel must hand ALL those segments to the saturated fix-up kernel.  Expected result by scalar
+    arithmetic: (sum of scalars) * G."""
+    rng = O.SplitMix64(31337)
+    n = 1 << 12
+    g = O.g1_mul(O.G1_GEN, rng.field())
+    sc = _rand_fr(rng, n)
+    sc[5] = (-sc[4]) % O.R      # exact cancellation inside buckets
+    sc[7] = sc[6]               # identical digit patterns: doublings in every window
+    B = cozk.Bases.upload(ctx, [g] * n, precompute=True)
+    got = B.msm(cozk.Vec.from_ints(ctx, sc))
+    assert got == O.g1_mul(g, sum(sc) % O.R)
+    # small scalars on repeated bases: one hot bucket made of equal points only
+    flags = [rng.next() & 1 for _ in range(n)]
+    got = B.msm(cozk.Vec.from_ints(ctx, flags, kind=cozk.SCALAR_U8))
+    assert got == O.g1_mul(g, sum(flags) % O.R)
