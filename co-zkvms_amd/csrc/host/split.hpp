@@ -51,26 +51,36 @@ static void prove_layer_split(SplitEnv& se, cozk_layer* layer, std::vector<fe>& 
     EqH eq;
     std::vector<uint64_t> w = to_abi(local);
     rc_check(cozk_spliteq_new(env.ctx, w.data(), n_loc, &eq.h), env.ctx, "spliteq_new");
-    std::vector<fe> rs;
-    for (int round = 0; round < n_loc; round++) {
-        uint64_t ev[12];
-        rc_check(cozk_layer_compute_cubic_evals(env.ctx, layer, eq.h, ev), env.ctx, "compute_cubic_evals");
-        std::vector<fe> msg(3);
-        for (int i = 0; i < 3; i++) msg[i] = Fr::mul(fe_from_u64x4(ev + 4 * i), s_w);
-        Writer wr;
-        wr.vec_fr(msg);
-        env.star->send_response(wr.b);
-        Bytes req = env.star->receive_request();
-        Reader rd(req);
-        fe r_j = rd.fr();
-        rs.push_back(r_j);
-        uint64_t rr[4];
-        fe_to_u64x4(r_j, rr);
-        rc_check(cozk_layer_bind(env.ctx, layer, rr), env.ctx, "layer_bind");
-        rc_check(cozk_spliteq_bind(env.ctx, eq.h, rr), env.ctx, "spliteq_bind");
-    }
+    // the local rounds run behind the ABI (per-round launches, then the resident kernel for the tail of the chunk)
+    struct Cb {
+        WorkerEnv* env;
+        fe s_w;
+        std::string error;
+        static int fn(void* user, int, const uint64_t ev[12], uint64_t r_out[4]) {
+            Cb* c = static_cast<Cb*>(user);
+            try {
+                std::vector<fe> msg(3);
+                for (int i = 0; i < 3; i++) msg[i] = Fr::mul(fe_from_u64x4(ev + 4 * i), c->s_w);
+                Writer wr;
+                wr.vec_fr(msg);
+                c->env->star->send_response(wr.b);
+                Bytes req = c->env->star->receive_request();
+                Reader rd(req);
+                fe_to_u64x4(rd.fr(), r_out);
+                return 0;
+            } catch (const std::exception& e) {
+                c->error = e.what();
+                return 1;
+            }
+        }
+    } cb{&env, s_w, {}};
+    std::vector<uint64_t> rbuf((size_t)4 * (n_loc > 0 ? n_loc : 1));
     uint64_t fc[16];
-    rc_check(cozk_layer_final_claims(env.ctx, layer, fc), env.ctx, "final_claims");
+    int st = cozk_layer_prove_rounds_evals(env.ctx, layer, eq.h, n_loc, Cb::fn, &cb, rbuf.data(), fc);
+    if (st != COZK_OK && !cb.error.empty()) throw CozkError(COZK_ERR_INTERNAL, cb.error);
+    rc_check(st, env.ctx, "layer_prove_rounds_evals");
+    std::vector<fe> rs;
+    for (int j = 0; j < n_loc; j++) rs.push_back(fe_from_u64x4(rbuf.data() + 4 * j));
     Writer wf;
     for (int i = 0; i < 4; i++) wf.fr(fe_from_u64x4(fc + 4 * i));
     env.star->send_response(wf.b);

@@ -1920,6 +1920,35 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
     });
 }
 
+// cozk_layer_prove_rounds for a worker sub-net, which cannot derive g(1) from the (global) previous claim and sends
+// the raw sums g(0), g(2), g(3) instead (as cozk_layer_compute_cubic_evals).  Same machinery: the round polynomial
+// through (g0, -g0, g2, g3) -- i.e. previous claim 0 -- is evaluated back at 0, 2, 3 for the callback.
+namespace {
+struct EvalsShim {
+    cozk_round_evals_cb cb;
+    void* user;
+};
+int evals_shim_cb(void* user, int round, const uint64_t coeffs[16], uint64_t r_out[4], uint64_t next_claim_out[4]) {
+    EvalsShim* sh = static_cast<EvalsShim*>(user);
+    std::vector<fe> cf(4);
+    for (int i = 0; i < 4; i++) cf[i] = fe_from_u64x4(coeffs + 4 * i);
+    uint64_t ev[12];
+    fe_to_u64x4(cf[0], ev);
+    auto horner = [&](const fe& x) { return Fr::add(cf[0], Fr::mul(x, Fr::add(cf[1], Fr::mul(x, Fr::add(cf[2], Fr::mul(x, cf[3])))))); };
+    fe_to_u64x4(horner(Fr::from_u64(2)), ev + 4);
+    fe_to_u64x4(horner(Fr::from_u64(3)), ev + 8);
+    for (int i = 0; i < 4; i++) next_claim_out[i] = 0;
+    return sh->cb(sh->user, round, ev, r_out);
+}
+}  // namespace
+int cozk_layer_prove_rounds_evals(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, int num_rounds, cozk_round_evals_cb cb, void* user,
+                                  uint64_t* out_r, uint64_t final_claims[16]) {
+    if (!cb) return COZK_ERR_INVALID_ARG;
+    EvalsShim sh{cb, user};
+    const uint64_t zero[4] = {0, 0, 0, 0};
+    return cozk_layer_prove_rounds(ctx, l, e, zero, num_rounds, evals_shim_cb, &sh, out_r, final_claims);
+}
+
 // the raw additive sums g(0), g(2), g(3) of compute_cubic, for a worker sub-net that cannot derive g(1) from
 // the (global) previous claim: the coordinator inserts claim - g(0), as the reference does for the primary
 // sumcheck (jolt/vm/instruction_lookups/worker.rs:593-597, coordinator.rs:131-132)

@@ -245,6 +245,12 @@ typedef int (*cozk_round_cb)(void* user, int round, const uint64_t coeffs[16], u
 int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* eq, const uint64_t claim[4],
                             int num_rounds, cozk_round_cb cb, void* user, uint64_t* out_r,
                             uint64_t final_claims[16]);
+/* the same loop for a worker sub-net (jolt/vm/instruction_lookups/worker.rs:593-597): the callback gets the raw sums
+ * g(0), g(2), g(3) of its chunk -- the coordinator inserts g(1) = claim - g(0) -- and returns the challenge */
+typedef int (*cozk_round_evals_cb)(void* user, int round, const uint64_t evals[12], uint64_t r_out[4]);
+int cozk_layer_prove_rounds_evals(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* eq, int num_rounds,
+                                  cozk_round_evals_cb cb, void* user, uint64_t* out_r,
+                                  uint64_t final_claims[16]);
 /* raw sums g(0), g(2), g(3) of compute_cubic (12 u64) for worker sub-nets: the coordinator inserts
  * claim - g(0) itself, as for the reference's primary sumcheck (instruction_lookups/worker.rs:593-597) */
 int cozk_layer_compute_cubic_evals(cozk_ctx* ctx, const cozk_layer* l, const cozk_spliteq* eq,
