@@ -861,6 +861,20 @@ void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, co
                 s += P;
             }
         }
+        // the first set's sort has nothing to hide behind: start with the cheapest one (fewest references)
+        if (sets.size() > 2) {
+            size_t best = 0;
+            uint64_t best_m = ~0ull;
+            for (size_t i = 0; i < sets.size(); i++) {
+                uint64_t m = 0;
+                for (size_t p = 0; p < sets[i].P; p++) m += (uint64_t)ns[t0 + sets[i].s + p] * kind_nwin(kinds[t0 + sets[i].s + p]);
+                if (m < best_m) {
+                    best_m = m;
+                    best = i;
+                }
+            }
+            std::rotate(sets.begin(), sets.begin() + best, sets.begin() + best + 1);
+        }
         static const bool pipeline = getenv("COZK_MSM_SERIAL") == nullptr;
         hipStream_t side = st;
         if (pipeline && sets.size() > 1) {
