@@ -144,7 +144,8 @@ static __device__ __forceinline__ xyzz9 xyzz9_from_affine(const f9& qx, const f9
 
 // acc += (qx, qy), EFD madd-2008-s.  Returns false (acc untouched) when PP == 0 mod p, i.e. P == +-Q.
 // Value bounds in units of p (product of < A and < B gives < 1 + A B / 169), limb bounds in brackets:
-//   in : X < 6, Y < 2, ZZ, ZZZ < 1.05, all normalised [2^29]; qx, qy < 1 canonical
+//   in : X < 6, Y < 2, ZZ, ZZZ < 1.05, all normalised [2^29]; qx < 1 canonical; qy < 1 canonical, or 2p - y for a
+//        negative digit (value < 2, limbs [2^30]: S2 < 1.02, column sums of qy * ZZZ <= 9 * 2^59 + 9 * 2^58)
 //   U2, S2 < 1.01                               Pd = U2 + 7p - X < 8.01, Rd = S2 + 3p - Y < 4.01   -> normalised
 //   PP < 1.38, RR < 1.10, PPP < 1.07, Q < 1.05   X3 = RR + 4p - PPP - 2Q < 5.1 [2^29 + 2^31]       -> normalised
 //   T = Q + 7p - X3 < 8.05 [3 * 2^29];           NY = 3p - Y [2^30]

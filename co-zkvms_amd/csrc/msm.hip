@@ -431,8 +431,11 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restri
         uint32_t ref = refs[e];
         g1_affine p = affine_load(table + (ref & 0x7fffffffu));
         if (G1::is_inf(p)) continue;
-        if (ref >> 31) p.y = Fq::neg(p.y);
         f9 qx = f9_from_fe(p.x), qy = f9_from_fe(p.y);
+        if (ref >> 31) {  // negative digit: -y as 2p - y, limb-wise (limbs < 2^30, value < 2p: fine as a product operand)
+#pragma unroll
+            for (int i = 0; i < 9; i++) qy.l[i] = F9_C2[i] - qy.l[i];
+        }
         if (!have) {
             acc = xyzz9_from_affine(qx, qy);
             have = true;
