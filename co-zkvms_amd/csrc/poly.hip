@@ -134,6 +134,35 @@ __global__ void __launch_bounds__(PT) k_poly_lincomb(const fe* const* __restrict
     sh_store<NC>(oa, ob, i, acc);
 }
 
+// the same with the (<= 16) operand pointers passed by value in the kernel arguments: the opening-reduction
+// sumcheck calls this once per round, and four metadata uploads + a drain per round cost more than the kernel
+struct OpenQuadArgs {
+    const fe* a[16];
+    const fe* b[16];
+    const fe* eq[16];
+    size_t half[16];
+};
+template <int NC>
+__global__ void __launch_bounds__(PT) k_open_quadratic_args(OpenQuadArgs args, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    const fe* a = args.a[blockIdx.y];
+    const fe* b = NC == 2 ? args.b[blockIdx.y] : nullptr;
+    const fe* eq = args.eq[blockIdx.y];
+    size_t h = args.half[blockIdx.y];
+    fe e0 = Fr::zero(), e2 = Fr::zero();
+    for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < h; i += (size_t)gridDim.x * PT) {
+        fe q0 = fe_load(eq + i), q1 = fe_load(eq + i + h);
+        fe p0 = sh_ab_sum<NC>(sh_load<NC>(a, b, i)), p1 = sh_ab_sum<NC>(sh_load<NC>(a, b, i + h));
+        e0 = Fr::add(e0, Fr::mul(p0, q0));
+        fe pb2 = Fr::sub(Fr::dbl(p1), p0), qb2 = Fr::sub(Fr::dbl(q1), q0);
+        e2 = Fr::add(e2, Fr::mul(pb2, qb2));
+    }
+    e0 = fr_block_sum(e0, sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)(2 * blockIdx.y) * gridDim.x + blockIdx.x, e0);
+    e2 = fr_block_sum(e2, sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)(2 * blockIdx.y + 1) * gridDim.x + blockIdx.x, e2);
+}
+
 // K11 leaf fingerprints (compute_leaves of the three memory-checking instances, e.g.
 // co-jolt/src/jolt/vm/bytecode/worker.rs:57-100, read_write_memory/worker.rs:207-260):
 //   leaf[i] = sum_k c_k * col_k[i]  (compact public columns, CompactPolynomial::field_mul)
@@ -1318,14 +1347,26 @@ int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys, cons
         size_t* dh = (size_t*)(de + k);
         fe* partial = (fe*)(((uintptr_t)(dh + k) + 31) & ~(uintptr_t)31);
         fe* res = result_slot(ctx, 2 * k);
-        HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(de, he.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(dh, hh.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
         dim3 grid(gx, (unsigned)k);
-        if (mode == COZK_MODE_REP3) k_open_quadratic<2><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
-        else k_open_quadratic<1><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
+        if (k <= 16) {
+            OpenQuadArgs args;
+            for (size_t i = 0; i < 16; i++) {
+                args.a[i] = i < k ? ha[i] : nullptr;
+                args.b[i] = i < k ? hb[i] : nullptr;
+                args.eq[i] = i < k ? he[i] : nullptr;
+                args.half[i] = i < k ? hh[i] : 0;
+            }
+            if (mode == COZK_MODE_REP3) k_open_quadratic_args<2><<<grid, PT, 0, ctx->stream>>>(args, partial);
+            else k_open_quadratic_args<1><<<grid, PT, 0, ctx->stream>>>(args, partial);
+        } else {
+            HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(de, he.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipMemcpyAsync(dh, hh.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
+            HIP_TRY(hipStreamSynchronize(ctx->stream));
+            if (mode == COZK_MODE_REP3) k_open_quadratic<2><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
+            else k_open_quadratic<1><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
+        }
         k_finish_sums<<<(unsigned)(2 * k), PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
         HIP_TRY(hipGetLastError());
         std::vector<fe> h(2 * k);
