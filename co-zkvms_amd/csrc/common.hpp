@@ -80,11 +80,11 @@ struct MsmSortWs {
 };
 struct MsmWorkspace {
     MsmSortWs sort[2];
-    DevBuf offB, offC, partA, partB, bsum, chunk, grp, out, ptrs, exc, blk;
+    DevBuf offB, offC, partA, partB, bsum, chunk, grp, out, ptrs, exc, blk, perm, offP;
     hipEvent_t fork = nullptr;
     void release() {
         for (MsmSortWs& s : sort) s.release();
-        for (DevBuf* b : {&offB, &offC, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs, &exc, &blk}) b->release();
+        for (DevBuf* b : {&offB, &offC, &partA, &partB, &bsum, &chunk, &grp, &out, &ptrs, &exc, &blk, &perm, &offP}) b->release();
         if (fork) (void)hipEventDestroy(fork);
         fork = nullptr;
     }

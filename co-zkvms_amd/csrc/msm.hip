@@ -242,13 +242,16 @@ __global__ void __launch_bounds__(LTPB) k_msm_scatter_lds(const MsmPolyDesc* __r
 static constexpr uint32_t SCAN_PER_BLOCK = 1024;
 
 template <bool FROM_OFFSETS>
-static __device__ __forceinline__ void scan_load4(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t b0, uint32_t c[4]) {
+static __device__ __forceinline__ void scan_load4(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t b0, uint32_t c[4],
+                                                  const uint32_t* __restrict__ perm) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         uint32_t b = b0 + k;
         if (b >= nb) c[k] = 0;
-        else if (FROM_OFFSETS) c[k] = (in[b + 1] - in[b] + L - 1u) / L;
-        else c[k] = in[b];
+        else if (FROM_OFFSETS) {
+            uint32_t q = perm ? perm[b] : b;  // with a permutation: the items of position b are those of entry perm[b]
+            c[k] = (in[q + 1] - in[q] + L - 1u) / L;
+        } else c[k] = in[b];
     }
 }
 
@@ -271,10 +274,11 @@ static __device__ __forceinline__ uint32_t block_exclusive_scan_256(uint32_t v, 
 }
 
 template <bool FROM_OFFSETS>
-__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t* __restrict__ bsums) {
+__global__ void __launch_bounds__(256) k_scan_sums(const uint32_t* __restrict__ in, uint32_t nb, uint32_t L, uint32_t* __restrict__ bsums,
+                                                 const uint32_t* __restrict__ perm) {
     __shared__ uint32_t sh4[4];
     uint32_t c[4];
-    scan_load4<FROM_OFFSETS>(in, nb, L, blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4, c);
+    scan_load4<FROM_OFFSETS>(in, nb, L, blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4, c, perm);
     uint32_t tot;
     (void)block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], sh4, &tot);
     if (threadIdx.x == 0) bsums[blockIdx.x] = tot;
@@ -307,11 +311,11 @@ __global__ void __launch_bounds__(1024) k_scan_top(uint32_t* bsums, uint32_t nbl
 
 template <bool FROM_OFFSETS>
 __global__ void __launch_bounds__(256) k_scan_final(const uint32_t* in, uint32_t nb, uint32_t L, const uint32_t* __restrict__ bsums,
-                                                  uint32_t* off, uint32_t* cursor) {
+                                                  uint32_t* off, uint32_t* cursor, const uint32_t* __restrict__ perm) {
     __shared__ uint32_t sh4[4];
     uint32_t c[4];
     uint32_t b0 = blockIdx.x * SCAN_PER_BLOCK + threadIdx.x * 4;
-    scan_load4<FROM_OFFSETS>(in, nb, L, b0, c);
+    scan_load4<FROM_OFFSETS>(in, nb, L, b0, c, perm);
     uint32_t run = bsums[blockIdx.x] + block_exclusive_scan_256(c[0] + c[1] + c[2] + c[3], sh4, nullptr);
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -397,11 +401,77 @@ static __device__ __forceinline__ uint32_t find_bucket_blk(const uint32_t* __res
     return find_bucket_in(off, lo, hi, t);
 }
 
+// ------------------------------------------------------------------ segments in order of their length
+// A wave runs as long as its longest lane.  Segments follow bucket order, and bucket fill is Poisson: on uniform Fr
+// digits (512 per bucket, 8-9 segments of 57..64) a wave idles 4.6 % of its lane-iterations, on the 32- and
+// 64-reference buckets of u16 / u32 columns 30 % (computed from the distributions; confirmed by the timings).
+// So the gather kernel walks the buckets in order of their segment length `per` (a counting sort over <= 65 keys;
+// order inside a key is irrelevant): the 64 lanes of a wave then run the same number of additions.  Outputs keep
+// their bucket-order slots, so the fold levels are unchanged.
+static constexpr uint32_t SEGKEYS = 128;
+static __device__ __forceinline__ uint32_t seg_key(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_seg, uint32_t b) {
+    uint32_t nseg = off_seg[b + 1] - off_seg[b];
+    if (nseg == 0) return 0;
+    uint32_t cnt = off_in[b + 1] - off_in[b];
+    uint32_t per = (cnt + nseg - 1) / nseg;
+    return per < SEGKEYS ? per : SEGKEYS - 1;
+}
+__global__ void __launch_bounds__(1024) k_seg_hist(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_seg, uint32_t nb,
+                                                uint32_t* __restrict__ bins) {
+    __shared__ uint32_t lh[SEGKEYS];
+    if (threadIdx.x < SEGKEYS) lh[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t b = blockIdx.x * 1024 + threadIdx.x;
+    if (b < nb) atomicAdd(&lh[seg_key(off_in, off_seg, b)], 1u);
+    __syncthreads();
+    if (threadIdx.x < SEGKEYS && lh[threadIdx.x]) atomicAdd(&bins[threadIdx.x], lh[threadIdx.x]);
+}
+// bins[k] <- first position of key k; longest segments first, so the tail of the launch is made of short lanes
+__global__ void k_seg_bins(uint32_t* bins) {
+    uint32_t run = 0;
+    for (int k = (int)SEGKEYS - 1; k >= 0; k--) {
+        uint32_t c = bins[k];
+        bins[k] = run;
+        run += c;
+    }
+}
+__global__ void __launch_bounds__(1024) k_seg_perm(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_seg, uint32_t nb,
+                                                uint32_t* __restrict__ bins, uint32_t* __restrict__ perm) {
+    __shared__ uint32_t lh[SEGKEYS], base[SEGKEYS];
+    if (threadIdx.x < SEGKEYS) lh[threadIdx.x] = 0;
+    __syncthreads();
+    uint32_t b = blockIdx.x * 1024 + threadIdx.x;
+    uint32_t key = 0, rank = 0;
+    if (b < nb) {
+        key = seg_key(off_in, off_seg, b);
+        rank = atomicAdd(&lh[key], 1u);
+    }
+    __syncthreads();
+    if (threadIdx.x < SEGKEYS && lh[threadIdx.x]) base[threadIdx.x] = atomicAdd(&bins[threadIdx.x], lh[threadIdx.x]);
+    __syncthreads();
+    if (b < nb) perm[base[key] + rank] = b;
+}
+
 // ------------------------------------------------------------------ bucket accumulation
 // level 0: gather affine SRS/table points by reference -- THE dominant kernel of the whole path.
 // Segment t of the balanced split: the bucket's cnt items go to its nseg = ceil(cnt / L) segments in equal shares
 // (ceil(cnt / nseg) each) instead of nseg-1 full segments and a short one, so the lanes of a wave run the same
 // number of iterations (the short remainders idled ~6 % of the lanes).
+// permuted walk: lane t is segment (t - offp[pos]) of bucket perm[pos], pos = the position whose range of offp holds t;
+// `slot` = where the segment's partial sum goes (bucket order: off_out[b] + s)
+static __device__ __forceinline__ void segment_range_perm(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
+                                                          const uint32_t* __restrict__ offp, const uint32_t* __restrict__ perm, uint32_t nb, uint32_t t,
+                                                          const uint32_t* __restrict__ blk, uint32_t& begin, uint32_t& end, uint32_t& slot) {
+    uint32_t pos = blk ? find_bucket_blk(offp, nb, blk, t) : find_bucket(offp, nb, t);
+    uint32_t b = perm[pos];
+    uint32_t s = t - offp[pos];
+    uint32_t cnt = off_in[b + 1] - off_in[b];
+    uint32_t nseg = off_out[b + 1] - off_out[b];
+    uint32_t per = (cnt + nseg - 1) / nseg;
+    begin = off_in[b] + min(s * per, cnt);
+    end = off_in[b] + min((s + 1) * per, cnt);
+    slot = off_out[b] + s;
+}
 static __device__ __forceinline__ void segment_range(const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out, uint32_t nb,
                                                      uint32_t t, uint32_t& begin, uint32_t& end, const uint32_t* __restrict__ blk = nullptr) {
     uint32_t b = blk ? find_bucket_blk(off_out, nb, blk, t) : find_bucket(off_out, nb, t);
@@ -443,12 +513,13 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict_
 __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
                                                     const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                                                     uint32_t nb, g1_xyzz* __restrict__ out, uint32_t* __restrict__ exc,
-                                                    const uint32_t* __restrict__ blk) {
+                                                    const uint32_t* __restrict__ blk, const uint32_t* __restrict__ offp,
+                                                    const uint32_t* __restrict__ perm) {
     uint32_t t = blockIdx.x * TPB + threadIdx.x;
     uint32_t total = off_out[nb];
     if (t >= total) return;
-    uint32_t begin, end;
-    segment_range(off_in, off_out, nb, t, begin, end, blk);
+    uint32_t begin, end, slot;
+    segment_range_perm(off_in, off_out, offp, perm, nb, t, blk, begin, end, slot);
     xyzz9 acc;
     bool have = false;
     for (uint32_t e = begin; e < end; e++) {
@@ -468,17 +539,18 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restri
             return;
         }
     }
-    xyzz_store(out + t, have ? xyzz9_to_xyzz(acc) : G1::identity());
+    xyzz_store(out + slot, have ? xyzz9_to_xyzz(acc) : G1::identity());
 }
 __global__ void __launch_bounds__(TPB) k_msm_accum0_fix(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
                                                      const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
-                                                     uint32_t nb, g1_xyzz* __restrict__ out, const uint32_t* __restrict__ exc) {
+                                                     uint32_t nb, g1_xyzz* __restrict__ out, const uint32_t* __restrict__ exc,
+                                                     const uint32_t* __restrict__ offp, const uint32_t* __restrict__ perm) {
     uint32_t n = exc[0];
     for (uint32_t q = blockIdx.x * TPB + threadIdx.x; q < n; q += gridDim.x * TPB) {  // every lane reaches the end of the queue
         uint32_t t = exc[1 + q];
-        uint32_t begin, end;
-        segment_range(off_in, off_out, nb, t, begin, end);
-        xyzz_store(out + t, gather_segment(table, refs, begin, end));
+        uint32_t begin, end, slot;
+        segment_range_perm(off_in, off_out, offp, perm, nb, t, nullptr, begin, end, slot);
+        xyzz_store(out + slot, gather_segment(table, refs, begin, end));
     }
 }
 
@@ -668,16 +740,17 @@ static MsmSetPlan msm_plan(const cozk_bases* bases, const size_t* offsets, const
     return pl;
 }
 
-static void msm_scan(hipStream_t st, uint32_t* bsums, uint32_t nb, bool from_offsets, const uint32_t* in, uint32_t L, uint32_t* off, uint32_t* cursor) {
+static void msm_scan(hipStream_t st, uint32_t* bsums, uint32_t nb, bool from_offsets, const uint32_t* in, uint32_t L, uint32_t* off, uint32_t* cursor,
+                     const uint32_t* perm = nullptr) {
     const uint32_t nscan_blocks = (nb + SCAN_PER_BLOCK - 1) / SCAN_PER_BLOCK;
     if (from_offsets) {
-        k_scan_sums<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+        k_scan_sums<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, perm);
         k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
-        k_scan_final<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+        k_scan_final<true><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor, perm);
     } else {
-        k_scan_sums<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums);
+        k_scan_sums<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, nullptr);
         k_scan_top<<<1, 1024, 0, st>>>(bsums, nscan_blocks, off + nb);
-        k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor);
+        k_scan_final<false><<<nscan_blocks, 256, 0, st>>>(in, nb, L, bsums, off, cursor, nullptr);
     }
 }
 
@@ -790,10 +863,21 @@ static void msm_accumulate(cozk_ctx* ctx, MsmSortWs& sw, const MsmSetPlan& pl, c
         ws.exc.reserve((size_t)(maxseg0 + 2) * 4);
         uint32_t* exc = ws.exc.as<uint32_t>();
         HIP_TRY(hipMemsetAsync(exc, 0, 4, st));
+        // walk the buckets in order of their segment length (see "segments in order of their length")
+        ws.perm.reserve((size_t)nb * 4);
+        ws.offP.reserve((size_t)(nb + 1) * 4 + SEGKEYS * 4);
+        uint32_t* perm = ws.perm.as<uint32_t>();
+        uint32_t* offP = ws.offP.as<uint32_t>();
+        uint32_t* bins = offP + nb + 1;
+        HIP_TRY(hipMemsetAsync(bins, 0, SEGKEYS * 4, st));
+        k_seg_hist<<<cdiv(nb, 1024), 1024, 0, st>>>(off0, offA, nb, bins);
+        k_seg_bins<<<1, 1, 0, st>>>(bins);
+        k_seg_perm<<<cdiv(nb, 1024), 1024, 0, st>>>(off0, offA, nb, bins, perm);
+        msm_scan(st, ws.ptrs.as<uint32_t>(), nb, true, offA, 1, offP, nullptr, perm);  // segment offsets in walking order
         const uint32_t nblk0 = cdiv(maxseg0, TPB);
-        k_block_buckets<<<cdiv(nblk0 + 1, 256), 256, 0, st>>>(offA, nb, nblk0, blk);
-        k_msm_accum0_f9<<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk);
-        k_msm_accum0_fix<<<256, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc);
+        k_block_buckets<<<cdiv(nblk0 + 1, 256), 256, 0, st>>>(offP, nb, nblk0, blk);
+        k_msm_accum0_f9<<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
+        k_msm_accum0_fix<<<256, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, offP, perm);
     } else {
         k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
     }
