@@ -141,7 +141,8 @@ def main():
     # separate runs; profiles/r1_pmc_hbm.json).  bench.py cannot run rocprofv3 on itself, so this is the
     # per-launch average of the same command at the same sizes, reported only when sizes match the default.
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]["k_msm_accum0_f9"]
+        pk = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_hbm.json")))["kernels"]
+        pmc = next(v for k, v in pk.items() if "k_msm_accum0_f9" in k)
         if log_n == 20:
             roofline["traffic"] = int((pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024)
             roofline["traffic_note"] = ("FETCH_SIZE+WRITE_SIZE per launch, raw (uncalibrated for 64-B gathers); ~10x the algorithmic bytes "

@@ -176,6 +176,7 @@ struct cozk_bases {
     size_t n;           // number of SRS points
     int nwin;           // 16 if a window table was precomputed, else 1
     g1_affine* table;   // [nwin][n]: table[w][i] = 2^(16 w) * G_i   (table[0] = the points themselves)
+    bool has_inf = true;  // some table entry is the point at infinity (set by build_window_table; the gather kernel then tests for it)
 };
 
 struct cozk_vec {       // device array of field elements / small scalars

@@ -510,6 +510,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict_
 // The same gather in 9 x 29-bit unsaturated limbs (fq9.cuh): no carry instructions in the products, no
 // conditional subtractions anywhere.  A segment that meets P == +-Q (repeated SRS points, cancelling digits) is
 // queued in `exc` ([0] = count, [1..] = segment ids) and redone by k_msm_accum0_fix with the saturated formulas.
+template <bool CHECK_INF>
 __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
                                                     const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                                                     uint32_t nb, g1_xyzz* __restrict__ out, uint32_t* __restrict__ exc,
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restri
     for (uint32_t e = begin; e < end; e++) {
         uint32_t ref = refs[e];
         g1_affine p = affine_load(table + (ref & 0x7fffffffu));
-        if (G1::is_inf(p)) continue;
+        if (CHECK_INF && G1::is_inf(p)) continue;  // tables without a point at infinity (the usual SRS) skip the test
         f9 qx = f9_from_fe(p.x), qy = f9_from_fe(p.y);
         if (ref >> 31) {  // negative digit: -y as 2p - y, limb-wise (limbs < 2^30, value < 2p: fine as a product operand)
 #pragma unroll
@@ -685,12 +686,26 @@ __global__ void __launch_bounds__(TPB) k_pair_sums(const g1_affine* __restrict__
 // ------------------------------------------------------------------ host orchestration
 static inline uint32_t cdiv(uint64_t a, uint64_t b) { return (uint32_t)((a + b - 1) / b); }
 
+// *flag = 1 if any of the n points is the point at infinity, (0, 0)
+__global__ void __launch_bounds__(TPB) k_any_infinity(const g1_affine* __restrict__ pts, size_t n, uint32_t* __restrict__ flag) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n && G1::is_inf(affine_load(pts + i))) atomicOr(flag, 1u);
+}
 static void build_window_table(cozk_ctx* ctx, cozk_bases* b) {
     for (int w = 1; w < b->nwin; w++) {
         k_precompute_window<<<cdiv(b->n, TPB), TPB, 0, ctx->stream>>>(b->table + (size_t)(w - 1) * b->n,
                                                                      b->table + (size_t)w * b->n, b->n);
     }
     HIP_TRY(hipGetLastError());
+    // 2^(16 w) P is the point at infinity only if P is (prime-order group): checking the points themselves covers the table
+    ctx->scratch.reserve(64);
+    uint32_t* flag = ctx->scratch.as<uint32_t>();
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, ctx->stream));
+    k_any_infinity<<<cdiv(b->n, TPB), TPB, 0, ctx->stream>>>(b->table, b->n, flag);
+    uint32_t h = 1;
+    HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    b->has_inf = h != 0;
 }
 
 #define KIND_DISPATCH(kind, CALL)                                              \
@@ -876,7 +891,10 @@ static void msm_accumulate(cozk_ctx* ctx, MsmSortWs& sw, const MsmSetPlan& pl, c
         msm_scan(st, ws.ptrs.as<uint32_t>(), nb, true, offA, 1, offP, nullptr, perm);  // segment offsets in walking order
         const uint32_t nblk0 = cdiv(maxseg0, TPB);
         k_block_buckets<<<cdiv(nblk0 + 1, 256), 256, 0, st>>>(offP, nb, nblk0, blk);
-        k_msm_accum0_f9<<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
+        if (bases->has_inf)
+            k_msm_accum0_f9<true><<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
+        else
+            k_msm_accum0_f9<false><<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
         k_msm_accum0_fix<<<256, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, offP, perm);
     } else {
         k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
