@@ -315,6 +315,70 @@ __global__ void __launch_bounds__(PT) k_layer_cubic(const fe* __restrict__ a, co
     if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, s3);
 }
 
+// bind + the next round's cubic sums in ONE pass over a large layer: a lane reads 8 unbound elements, writes the 4
+// bound ones and adds their chunk's three terms (eq tables already folded by the caller).  The separate kernels
+// read the layer twice and write it once per round (80 B per element, plain); this reads once and writes once (48).
+template <int NC, int NESTED>
+__global__ void __launch_bounds__(PT) k_layer_bind_cubic(const fe* __restrict__ ia, const fe* __restrict__ ib, fe* oa, fe* ob, size_t len_in, fe r,
+                                                      const fe* __restrict__ E1, size_t E1_half, const fe* __restrict__ E2, size_t E2_len,
+                                                      fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    const size_t nch_in = (len_in + 3) / 4;      // input chunks of 4 -> 2 bound elements each
+    const size_t len_out = 2 * nch_in;
+    const size_t nch_out = (len_out + 3) / 4;    // output chunks of 4 bound elements = 2 input chunks
+    size_t limit = NESTED ? E1_half * E2_len : E2_len / 2;
+    fe s0 = Fr::zero(), s2 = Fr::zero(), s3 = Fr::zero();
+    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch_out; c += (size_t)gridDim.x * PT) {
+        Sh<NC> v[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            size_t ci = 2 * c + h;
+            if (ci < nch_in) {
+                Sh<NC> u0 = sh_load_or_zero<NC>(ia, ib, 4 * ci, len_in), u1 = sh_load_or_zero<NC>(ia, ib, 4 * ci + 1, len_in);
+                Sh<NC> u2 = sh_load_or_zero<NC>(ia, ib, 4 * ci + 2, len_in), u3 = sh_load_or_zero<NC>(ia, ib, 4 * ci + 3, len_in);
+                v[2 * h] = sh_lerp<NC>(u0, u2, r);
+                v[2 * h + 1] = sh_lerp<NC>(u1, u3, r);
+                sh_store<NC>(oa, ob, 2 * ci, v[2 * h]);
+                sh_store<NC>(oa, ob, 2 * ci + 1, v[2 * h + 1]);
+            } else {
+                for (int k = 0; k < NC; k++) v[2 * h].c[k] = v[2 * h + 1].c[k] = Fr::zero();
+            }
+        }
+        if (c < limit) {  // zip() stops at the shorter side (k_layer_cubic)
+            fe e[3];
+            fe scale;
+            if (NESTED) {
+                size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+                eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
+                scale = fe_load(E2 + x2);
+            } else {
+                eq3(fe_load(E2 + 2 * c), fe_load(E2 + 2 * c + 1), e);
+            }
+            Sh<NC> l0 = v[0], r0 = v[1], l1 = v[2], r1 = v[3];
+            Sh<NC> ml = sh_sub<NC>(l1, l0), mr = sh_sub<NC>(r1, r0);
+            Sh<NC> l2 = sh_add<NC>(l1, ml), r2 = sh_add<NC>(r1, mr);
+            Sh<NC> l3 = sh_add<NC>(l2, ml), r3 = sh_add<NC>(r2, mr);
+            fe t0 = Fr::mul(sh_local_mul<NC>(l0, r0), e[0]);
+            fe t2 = Fr::mul(sh_local_mul<NC>(l2, r2), e[1]);
+            fe t3 = Fr::mul(sh_local_mul<NC>(l3, r3), e[2]);
+            if (NESTED) {
+                t0 = Fr::mul(t0, scale);
+                t2 = Fr::mul(t2, scale);
+                t3 = Fr::mul(t3, scale);
+            }
+            s0 = Fr::add(s0, t0);
+            s2 = Fr::add(s2, t2);
+            s3 = Fr::add(s3, t3);
+        }
+    }
+    s0 = fr_block_sum(s0, sh4);
+    if (threadIdx.x == 0) fe_store(partial + blockIdx.x, s0);
+    s2 = fr_block_sum(s2, sh4);
+    if (threadIdx.x == 0) fe_store(partial + gridDim.x + blockIdx.x, s2);
+    s3 = fr_block_sum(s3, sh4);
+    if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, s3);
+}
+
 // One whole sumcheck round of a SMALL layer in a single one-workgroup launch: bind the layer and the split-eq
 // tables with the previous challenge (k_layer_bind + SplitEqPolynomial::bind), then the cubic sums of the new
 // round (k_layer_cubic) and their block reduction straight into the pinned result slot.  The GKR proof is ~270
@@ -1768,13 +1832,53 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
                      uint64_t out_coeffs[16]) {
     if (!ctx || !l || !e || !prev_claim || !out_coeffs) return COZK_ERR_INVALID_ARG;
     if (l->len > ROUND_SMALL_MAX) {
-        if (r) {
-            int rc = cozk_layer_bind(ctx, l, r);
-            if (rc != COZK_OK) return rc;
-            rc = cozk_spliteq_bind(ctx, e, r);
-            if (rc != COZK_OK) return rc;
-        }
-        return cozk_layer_compute_cubic(ctx, l, e, prev_claim, out_coeffs);
+        if (!r) return cozk_layer_compute_cubic(ctx, l, e, prev_claim, out_coeffs);
+        // large layer: fold the eq tables, then bind and take the next round's sums in one pass (k_layer_bind_cubic)
+        int rc = cozk_spliteq_bind(ctx, e, r);
+        if (rc != COZK_OK) return rc;
+        return cozk_guard(ctx, [&] {
+            size_t nch_in = (l->len + 3) / 4;
+            size_t nout = 2 * nch_in;
+            int dst = 1 - l->cur;
+            if (l->cap[dst] < nout) {
+                for (int c = 0; c < 2; c++) {
+                    if (l->buf[dst][c]) ctx_dev_free(l->ctx, l->buf[dst][c]);
+                    l->buf[dst][c] = nullptr;
+                }
+                l->buf[dst][0] = dev_alloc_fe(nout);
+                if (l->mode == COZK_MODE_REP3) l->buf[dst][1] = dev_alloc_fe(nout);
+                l->cap[dst] = nout;
+            }
+            size_t nch_out = (nout + 3) / 4;
+            unsigned gx = grid_capped(nch_out);
+            if (gx > 1024) gx = 1024;
+            ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
+            fe* partial = ctx->scratch.as<fe>();
+            fe* res = result_slot(ctx, 3);
+            fe rr = fe_from_u64x4(r);
+            const fe *ia = l->buf[l->cur][0], *ib = l->buf[l->cur][1];
+            fe *oa = l->buf[dst][0], *ob = l->buf[dst][1];
+            const fe* E1 = e->E1[e->c1];
+            const fe* E2 = e->E2[e->c2];
+            bool nested = e->E1_len != 1;
+            if (l->mode == COZK_MODE_REP3) {
+                if (nested) k_layer_bind_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
+                else k_layer_bind_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, 0, E2, e->E2_len, partial);
+            } else {
+                if (nested) k_layer_bind_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
+                else k_layer_bind_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, rr, E1, 0, E2, e->E2_len, partial);
+            }
+            k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+            HIP_TRY(hipGetLastError());
+            l->cur = dst;
+            l->len = nout;
+            fe sres[3];
+            fetch_fe(ctx, res, 3, sres);
+            fe ev[4] = {sres[0], Fr::sub(fe_from_u64x4(prev_claim), sres[0]), sres[1], sres[2]};
+            fe cf[4];
+            unipoly_from_evals(ev, 4, cf);
+            for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], out_coeffs + 4 * i);
+        });
     }
     return cozk_guard(ctx, [&] {
         const fe *ia = l->buf[l->cur][0], *ib = l->buf[l->cur][1];
