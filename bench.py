@@ -40,6 +40,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the padded trace length (cycles)")
     ap.add_argument("--cpu-sample-log-n", type=int, default=16, help="trace length of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leaf-fingerprints", action="store_true",
+                    help="compute the grand-product leaves as K11 fingerprints of committed columns (not available with --shard worker)")
     ap.add_argument("--hub", choices=["shm", "gloo"], default="shm", help="transport of the per-round star messages (--shard worker)")
     ap.add_argument("--shard", choices=["worker", "segment"], default="worker",
                     help="N>1: one proof sharded as worker sub-nets (default) or N independent trace segments")
@@ -90,7 +92,8 @@ def main():
                 party.close()
         h = _H()
     else:
-        h = pkg.Harness(mode="plain", log_n=log_n, seed=dist.shard_seed(2026, rank), devices=(dev, dev, dev), **workload)
+        h = pkg.Harness(mode="plain", log_n=log_n, seed=dist.shard_seed(2026, rank), devices=(dev, dev, dev), leaf_fingerprints=args.leaf_fingerprints,
+                        **workload)
     t_setup = time.time() - t_setup
 
     # correctness gate (untimed): the assembled proof verifies (GKR, leaf evaluation, reduction sumcheck,

@@ -216,7 +216,12 @@ static void setup_party(cozk_harness* h, PartyState& ps) {
             ps.small_commit_vecs.push_back(VecH(view));
         }
     }
-    // grand-product leaves: gp_batch circuits x 2^gp_log_leaves interleaved entries
+    // grand-product leaves: gp_batch circuits x 2^gp_log_leaves interleaved entries (seeded random shares, unless
+    // they are computed per prove as fingerprints of the committed columns)
+    if (c.leaf_fingerprints) {
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        return;
+    }
     size_t nleaves = (size_t)c.gp_batch << c.gp_log_leaves;
     VecH la, lb;
     make_share_vectors(ctx, nleaves, c.seed + 500000ull, ps.party, c.mode, la, lb);
@@ -271,7 +276,55 @@ static void worker_main(cozk_harness* h, PartyState& ps, StarNetWorker* star, Ri
     ps.t_commit = t1 - t_start;
     // ---- 2. dense grand product (memory-checking shape, lasso/memory_checking/worker.rs:77-127)
     cozk_layer* lv = nullptr;
-    rc_check(cozk_layer_clone(ps.ctx, ps.leaves.h, &lv), ps.ctx, "layer_clone");  // stand-in for compute_leaves
+    LayerH fresh_leaves;  // fingerprint mode: this prove's leaves (kept for the leaf-evaluation check below)
+    if (c.leaf_fingerprints) {
+        // compute_leaves (K11): receive (gamma, tau), fingerprint the committed columns circuit by circuit
+        Bytes req = star->receive_request();
+        Reader rd(req);
+        fe gamma = rd.fr(), tau = rd.fr();
+        size_t N = h->N, nleaves = (size_t)c.gp_batch << c.gp_log_leaves;
+        cozk_vec *la = nullptr, *lb = nullptr;
+        rc_check(cozk_vec_alloc(ps.ctx, nleaves, COZK_SCALAR_FR, &la), ps.ctx, "vec_alloc");
+        VecH lah(la), lbh;
+        if (c.mode == COZK_MODE_REP3) {
+            rc_check(cozk_vec_alloc(ps.ctx, nleaves, COZK_SCALAR_FR, &lb), ps.ctx, "vec_alloc");
+            lbh = VecH(lb);
+        }
+        const int first_u16 = c.n_fr, first_u32 = c.n_fr + c.n_u16, first_flag = c.n_fr + c.n_u16 + c.n_u32;
+        for (int circ = 0; circ < c.gp_batch; circ++) {
+            std::vector<const cozk_vec*> cols;
+            std::vector<fe> cc;
+            fe g = gamma;
+            auto take = [&](int first, int count) {
+                if (count <= 0) return;
+                cols.push_back(ps.commit_vecs[(size_t)(first + circ % count)].h);
+                cc.push_back(g);
+                g = Fr::mul(g, gamma);
+            };
+            take(first_u16, c.n_u16);
+            take(first_u32, c.n_u32);
+            take(first_flag, c.n_flags);
+            const cozk_poly* shared[1] = {ps.polys[(size_t)(circ % c.n_fr)].h};
+            fe g_sh = g, g_w = Fr::mul(g, gamma);
+            std::vector<uint64_t> ccw = to_abi(cc);
+            uint64_t dsh[4], cst[4];
+            fe_to_u64x4(g_sh, dsh);
+            size_t base = (size_t)circ << c.gp_log_leaves;
+            fe_to_u64x4(Fr::neg(tau), cst);  // read leaves
+            rc_check(cozk_fingerprint_leaves(ps.ctx, cols.data(), ccw.data(), cols.size(), shared, dsh, 1, cst, c.mode, ps.party, lah.h, lbh.h, base, N),
+                     ps.ctx, "fingerprint_leaves");
+            fe_to_u64x4(Fr::sub(g_w, tau), cst);  // write leaves: + gamma^(k+1)
+            rc_check(cozk_fingerprint_leaves(ps.ctx, cols.data(), ccw.data(), cols.size(), shared, dsh, 1, cst, c.mode, ps.party, lah.h, lbh.h, base + N, N),
+                     ps.ctx, "fingerprint_leaves");
+        }
+        cozk_layer* fl = nullptr;
+        rc_check(cozk_layer_create(ps.ctx, c.mode, lah.h, lbh.h, 1, &fl), ps.ctx, "layer_create");
+        fresh_leaves = LayerH(fl);
+        rc_check(cozk_layer_clone(ps.ctx, fl, &lv), ps.ctx, "layer_clone");
+    } else {
+        rc_check(cozk_layer_clone(ps.ctx, ps.leaves.h, &lv), ps.ctx, "layer_clone");  // stand-in for compute_leaves
+    }
+    const cozk_layer* check_leaves = c.leaf_fingerprints ? fresh_leaves.h : ps.leaves.h;
     Rep3BatchedDenseGrandProduct gp = Rep3BatchedDenseGrandProduct::construct(env, LayerH(lv), (size_t)c.gp_batch);
     HIP_TRY(hipStreamSynchronize(ps.ctx->stream));
     double t2 = now_ms();
@@ -291,7 +344,7 @@ static void worker_main(cozk_harness* h, PartyState& ps, StarNetWorker* star, Ri
         rc_check(cozk_eq_evals(ps.ctx, rr.data(), (int)r_gp.size(), &chi), ps.ctx, "eq_evals");
         VecH chih(chi);
         cozk_poly* lp = nullptr;
-        rc_check(cozk_layer_as_poly(ps.ctx, ps.leaves.h, &lp), ps.ctx, "layer_as_poly");
+        rc_check(cozk_layer_as_poly(ps.ctx, check_leaves, &lp), ps.ctx, "layer_as_poly");
         PolyH lph(lp);
         uint64_t ev[4];
         const cozk_poly* arr[1] = {lph.h};
@@ -419,6 +472,13 @@ static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundl
         for (auto& cm : proof.commitments) tr.append_point(cm.g_product);
         for (auto& cm : proof.small_commitments) tr.append_point(cm.g_product);
     }
+    if (c.leaf_fingerprints) {  // receive_gamma_tau (lasso/memory_checking/worker.rs:85)
+        fe gamma = tr.challenge_scalar(), tau = tr.challenge_scalar();
+        Writer w;
+        w.fr(gamma);
+        w.fr(tau);
+        net.broadcast_request(w.b);
+    }
     fe gp_claim;
     std::vector<fe> r_gp;
     size_t num_layers = (size_t)c.gp_log_leaves;
@@ -449,6 +509,10 @@ static int coordinator_main(cozk_harness* h, StarNetCoordinator& net, ProofBundl
     Transcript vt("cozk-harness");
     for (auto& cm : proof.commitments) vt.append_point(cm.g_product);
     for (auto& cm : proof.small_commitments) vt.append_point(cm.g_product);
+    if (c.leaf_fingerprints) {
+        (void)vt.challenge_scalar();  // gamma, tau
+        (void)vt.challenge_scalar();
+    }
     fe v_claim;
     std::vector<fe> v_r;
     if (!verify_grand_product(proof.gp, vt, v_claim, v_r)) {
@@ -579,6 +643,9 @@ int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out) {
         while ((1 << gbits) < cfg->gp_batch) gbits++;
         COZK_REQUIRE(gbits + cfg->gp_log_leaves >= cfg->log_n, "harness: grand-product point shorter than the opening point");
         COZK_REQUIRE(cfg->n_fr + cfg->n_u16 + cfg->n_u32 + cfg->n_flags >= 1, "harness: no polynomials");
+        if (cfg->leaf_fingerprints)
+            COZK_REQUIRE(cfg->gp_log_leaves == cfg->log_n + 1 && cfg->n_fr >= 1 && cfg->log_workers == 0,
+                         "harness: leaf_fingerprints needs gp_log_leaves == log_n + 1, n_fr >= 1, log_workers == 0");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->N = (size_t)1 << cfg->log_n;
         COZK_REQUIRE(cfg->log_workers >= 0 && cfg->log_workers <= 3, "harness: log_workers must be 0..3");
@@ -725,6 +792,9 @@ int cozk_harness_create_participant(const cozk_harness_config* cfg, int local_pa
         int W = 1 << cfg->log_workers;
         COZK_REQUIRE(local_party >= 0 && local_party < np && local_worker >= 0 && local_worker < W, "harness_create_participant: bad (party, worker)");
         COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24 && cfg->gp_batch >= 1 && cfg->gp_log_leaves >= 1, "harness: bad shape");
+        if (cfg->leaf_fingerprints)
+            COZK_REQUIRE(cfg->gp_log_leaves == cfg->log_n + 1 && cfg->n_fr >= 1 && cfg->log_workers == 0,
+                         "harness: leaf_fingerprints needs gp_log_leaves == log_n + 1, n_fr >= 1, log_workers == 0");
         int gbits = 0;
         while ((1 << gbits) < cfg->gp_batch) gbits++;
         COZK_REQUIRE(gbits + cfg->gp_log_leaves >= cfg->log_n, "harness: grand-product point shorter than the opening point");

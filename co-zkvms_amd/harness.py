@@ -11,7 +11,8 @@ class HarnessConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("n_fr", ctypes.c_int), ("n_u16", ctypes.c_int),
                 ("n_u32", ctypes.c_int), ("n_flags", ctypes.c_int), ("n_small", ctypes.c_int), ("gp_batch", ctypes.c_int),
                 ("gp_log_leaves", ctypes.c_int), ("precompute", ctypes.c_int), ("devices", ctypes.c_int * 3),
-                ("seed", ctypes.c_uint64), ("log_workers", ctypes.c_int), ("worker_devices", ctypes.c_int * 8)]
+                ("seed", ctypes.c_uint64), ("log_workers", ctypes.c_int), ("worker_devices", ctypes.c_int * 8),
+                ("leaf_fingerprints", ctypes.c_int)]
 
 
 class HarnessResult(ctypes.Structure):
@@ -52,7 +53,8 @@ HARNESS_SYMBOLS = ["cozk_harness_create", "cozk_harness_error", "cozk_harness_de
 
 class Harness:
     def __init__(self, mode="plain", log_n=10, n_fr=4, n_u16=1, n_u32=1, n_flags=1, n_small=0, gp_batch=2,
-                 gp_log_leaves=None, precompute=True, devices=(0, 0, 0), seed=1, log_workers=0, worker_devices=None):
+                 gp_log_leaves=None, precompute=True, devices=(0, 0, 0), seed=1, log_workers=0, worker_devices=None,
+                 leaf_fingerprints=False):
         self._l = _decl()
         cfg = HarnessConfig()
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
@@ -66,6 +68,7 @@ class Harness:
         cfg.log_workers = log_workers
         wd = list(worker_devices) if worker_devices is not None else [devices[0]] * 8
         cfg.worker_devices = (ctypes.c_int * 8)(*(wd + [wd[-1]] * (8 - len(wd))))
+        cfg.leaf_fingerprints = 1 if leaf_fingerprints else 0
         self.cfg = cfg
         h = ctypes.c_void_p()
         rc = self._l.cozk_harness_create(ctypes.byref(cfg), ctypes.byref(h))

@@ -222,6 +222,7 @@ class DistributedParty:
         cfg.seed = cfgkw.get("seed", 1)
         cfg.log_workers = log_workers
         cfg.worker_devices = (ctypes.c_int * 8)(*([device] * 8))
+        cfg.leaf_fingerprints = 1 if cfgkw.get("leaf_fingerprints", False) else 0
         self.party, self.worker = party, worker
         self.nparties = 3 if mode == "rep3" else 1
         self.index = worker * self.nparties + party

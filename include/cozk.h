@@ -345,6 +345,12 @@ typedef struct cozk_harness_config {
                           of every polynomial and gp_batch / 2^log_workers circuits (reference: split_poly,
                           dense_mlpoly.rs:275-301; co-jolt/README.md:44).  0 = the single-worker path. */
     int worker_devices[8]; /* HIP device per worker index (in-process form) */
+    int leaf_fingerprints; /* 0: the grand-product leaves are seeded random shares (cloned per prove);
+                              1: compute_leaves (K11): after the commitments the coordinator sends (gamma, tau) and every
+                              circuit's leaves are fingerprints of committed columns -- read leaves gamma u16 + gamma^2 u32 +
+                              gamma^3 flag + gamma^k shared - tau over the N cycles, then the write leaves (+ gamma^(k+1)), as
+                              the bytecode instance lays them out (jolt/vm/bytecode/worker.rs:57-100).  Needs
+                              gp_log_leaves == log_n + 1, n_fr >= 1 and log_workers == 0. */
 } cozk_harness_config;
 typedef struct cozk_harness_result {
     int verified; /* 1 accepted, 0 rejected, -1 verifier not run */

@@ -90,7 +90,8 @@ def run(cfg):
         parts = _shares_of(seed + 300000 + 1000 * k, N >> 4, mode)
         small.append({"public": False, "parts": parts, "commit": [_a_of(p) for p in parts]})
     nleaves = cfg["gp_batch"] << cfg["gp_log_leaves"]
-    leaves = _shares_of(seed + 500000, nleaves, mode)
+    fingerprints = bool(cfg.get("leaf_fingerprints", False))
+    leaves = None if fingerprints else _shares_of(seed + 500000, nleaves, mode)
     tr = O.Transcript(b"cozk-harness")
     # ---- commit: shared = sum of parties' share commitments; public = P0's commitment
     def combine(plist):
@@ -108,6 +109,27 @@ def run(cfg):
     small_commitments = combine(small)
     for c in commitments + small_commitments:
         tr.append_point(c)
+    if fingerprints:
+        # compute_leaves (K11; harness.hip worker_main): per circuit the read leaves gamma u16 + gamma^2 u32 + gamma^3 flag
+        # + gamma^k shared - tau over the N cycles, then the write leaves (+ gamma^(k+1))
+        assert cfg["gp_log_leaves"] == nv + 1 and cfg["n_fr"] >= 1
+        gamma, tau = tr.challenge_scalar(), tr.challenge_scalar()
+        first_u16, first_u32 = cfg["n_fr"], cfg["n_fr"] + cfg["n_u16"]
+        first_flag = first_u32 + cfg["n_u32"]
+        leaves = [[] for _ in range(np_)]
+        for circ in range(cfg["gp_batch"]):
+            cols, cc, g = [], [], gamma
+            for first, count in ((first_u16, cfg["n_u16"]), (first_u32, cfg["n_u32"]), (first_flag, cfg["n_flags"])):
+                if count > 0:
+                    cols.append(polys[first + circ % count]["parts"][0])
+                    cc.append(g)
+                    g = g * gamma % R
+            g_sh, g_w = g, g * gamma % R
+            for q in range(np_):
+                shared = polys[circ % cfg["n_fr"]]["parts"][q]
+                party = None if mode == "plain" else q
+                leaves[q] += O.fingerprint_leaves(cols, cc, [shared], [g_sh], (-tau) % R, party)
+                leaves[q] += O.fingerprint_leaves(cols, cc, [shared], [g_sh], (g_w - tau) % R, party)
     # ---- grand product
     mask_ctr = 0
 

@@ -68,3 +68,26 @@ def test_large_2_16_plain_verifies(cozk):
     res = h.prove(verify=True)
     assert res.verified == 1, h.last_error()
     h.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "rep3"])
+def test_leaf_fingerprints_in_the_pipeline(cozk, mode):
+    """K11 wired in: the coordinator sends (gamma, tau) after the commitments and every circuit's leaves are
+    fingerprints of committed columns (cozk_fingerprint_leaves) instead of seeded random shares.  The proof is
+    bit-identical to the Python pipeline run the same way, for the plain prover and the 3-party Rep3 run."""
+    cfg = dict(log_n=5, n_fr=3, n_u16=2, n_u32=1, n_flags=1, n_small=0, gp_batch=4, gp_log_leaves=6, seed=77)
+    h = cozk.Harness(mode=mode, leaf_fingerprints=True, **cfg)
+    res = h.prove(verify=True)
+    assert res.verified == 1, h.last_error()
+    ref = pyharness.run(dict(cfg, mode=mode, leaf_fingerprints=True))
+    assert h.proof_bytes(res) == ref["proof_bytes"]
+    h.close()
+
+
+def test_leaf_fingerprints_2p16_verifies(cozk):
+    h = cozk.Harness(mode="plain", leaf_fingerprints=True, log_n=16, n_fr=8, n_u16=4, n_u32=2, n_flags=2, n_small=0, gp_batch=8,
+                     gp_log_leaves=17, seed=5)
+    r = h.prove(verify=True)
+    assert r.verified == 1, h.last_error()
+    assert bytes(h.prove(verify=False).proof_digest) == bytes(r.proof_digest)
+    h.close()
