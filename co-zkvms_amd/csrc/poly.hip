@@ -210,6 +210,38 @@ __global__ void __launch_bounds__(PT) k_fingerprint_leaves(const SmallCol* __res
     sh_store<NC>(oa, ob, i, acc);
 }
 
+// the usual shapes (<= 16 columns, <= 8 polynomials) travel by value in the kernel arguments: no staging, no drain
+struct FingerprintArgs {
+    SmallCol cols[16];
+    fe cs[16];
+    const fe* pa[8];
+    const fe* pb[8];
+    fe ds[8];
+};
+template <int NC>
+__global__ void __launch_bounds__(PT) k_fingerprint_leaves_args(FingerprintArgs a, int ks, int kp, fe constant, int pub_a, int pub_b, fe* oa, fe* ob,
+                                                             size_t n) {
+    size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
+    if (i >= n) return;
+    fe pub = constant;
+    for (int k = 0; k < ks; k++) {
+        uint64_t v = small_load(a.cols[k], i);
+        fe x = Fr::zero();
+        x.l[0] = (uint32_t)v;
+        x.l[1] = (uint32_t)(v >> 32);
+        pub = Fr::add(pub, Fr::mul(a.cs[k], x));
+    }
+    Sh<NC> acc;
+    for (int c = 0; c < NC; c++) acc.c[c] = Fr::zero();
+    for (int j = 0; j < kp; j++) {
+        if (a.pa[j]) acc.c[0] = Fr::add(acc.c[0], Fr::mul(fe_load(a.pa[j] + i), a.ds[j]));
+        if (NC == 2 && a.pb[j]) acc.c[NC - 1] = Fr::add(acc.c[NC - 1], Fr::mul(fe_load(a.pb[j] + i), a.ds[j]));
+    }
+    if (pub_a) acc.c[0] = Fr::add(acc.c[0], pub);
+    if (NC == 2 && pub_b) acc.c[NC - 1] = Fr::add(acc.c[NC - 1], pub);
+    sh_store<NC>(oa, ob, i, acc);
+}
+
 // quadratic opening-reduction round (compute_quadratic, opening_proof.rs:374-414): per opening
 // eval_0 = sum_i poly[i]*eq[i], eval_2 = sum_i (2 poly[i+h] - poly[i]) * (2 eq[i+h] - eq[i]);
 // partial[(2*y + e) * gridDim.x + x]; the (a+b)*TWO_INV conversion is folded into the finisher.
@@ -1349,6 +1381,28 @@ int cozk_fingerprint_leaves(cozk_ctx* ctx, const cozk_vec* const* cols, const ui
                 ha[j] = poly_a(p);
                 hb[j] = nullptr;
             }
+        }
+        fe cst0 = fe_from_u64x4(constant);
+        if (ks <= 16 && kp <= 8) {
+            FingerprintArgs fa;
+            memset(&fa, 0, sizeof fa);
+            for (size_t k = 0; k < ks; k++) {
+                fa.cols[k] = hcols[k];
+                fa.cs[k] = hcs[k];
+            }
+            for (size_t j = 0; j < kp; j++) {
+                fa.pa[j] = ha[j];
+                fa.pb[j] = hb[j];
+                fa.ds[j] = hds[j];
+            }
+            fe* oa0 = (fe*)out_a->d + offset;
+            if (mode == COZK_MODE_REP3)
+                k_fingerprint_leaves_args<2><<<grid_for(n), PT, 0, ctx->stream>>>(fa, (int)ks, (int)kp, cst0, party_id == 0, party_id == 1, oa0,
+                                                                                 (fe*)out_b->d + offset, n);
+            else
+                k_fingerprint_leaves_args<1><<<grid_for(n), PT, 0, ctx->stream>>>(fa, (int)ks, (int)kp, cst0, 1, 0, oa0, nullptr, n);
+            HIP_TRY(hipGetLastError());
+            return;
         }
         size_t meta = ks * sizeof(SmallCol) + 64 + (ks + kp) * sizeof(fe) + 64 + 2 * kp * sizeof(void*) + 64;
         ctx->scratch.reserve(meta);
