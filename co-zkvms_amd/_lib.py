@@ -104,6 +104,7 @@ SIGNATURES = {
     "cozk_layer_bind": (_i, [_vp, _vp, _vp]),
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_ctx_set_resident_rounds": (_i, [_vp, _i]),
+    "cozk_rep3_share_vec": (_i, [_vp, _vp, _u64, _u64, _i, _pp, _pp]),
     "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cozk_fingerprint_leaves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _sz, _sz]),
     "cozk_layer_prove_rounds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),

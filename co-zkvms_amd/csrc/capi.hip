@@ -227,6 +227,52 @@ int cozk_vec_free(cozk_vec* v) {
 size_t cozk_vec_len(const cozk_vec* v) { return v ? v->n : 0; }
 void* cozk_vec_device_ptr(const cozk_vec* v) { return v ? v->d : nullptr; }
 
+// Rep3 sharing of a secret vector on the device (rep3::share_field_element, mpc-core/src/protocols/rep3/arithmetic.rs:
+// 21-33; the witness scatter of jolt/vm/*/witness.rs generate_poly_shares_rep3): t0 = stream(seed0), t1 = stream(seed1),
+// t2 = v - t0 - t1; party 0 holds (t0, t2), party 1 (t1, t0), party 2 (t2, t1).  One fused pass, no temporaries.
+// (The reference's generate_poly_shares_rep3 repeats ONE random element over the whole vector, SURVEY 9: not copied.)
+static __device__ __forceinline__ fe stream_fr(uint64_t seed, size_t i) {
+    uint64_t s = seed + (uint64_t)i * 0xD1342543DE82EF95ull;
+    fe v;
+    for (;;) {
+        uint64_t w0 = splitmix_next(s), w1 = splitmix_next(s), w2 = splitmix_next(s);
+        uint64_t w3 = splitmix_next(s) & ((1ull << 62) - 1ull);
+        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
+        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
+        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
+        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
+        if (!Fr::geq_mod(v)) break;
+    }
+    return Fr::to_mont(v);
+}
+__global__ void k_rep3_share(const fe* __restrict__ v, size_t n, uint64_t seed0, uint64_t seed1, int party, fe* __restrict__ a, fe* __restrict__ b) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    fe t0 = stream_fr(seed0, i), t1 = stream_fr(seed1, i);
+    fe t2 = Fr::sub(Fr::sub(fe_load(v + i), t0), t1);
+    fe_store(a + i, party == 0 ? t0 : party == 1 ? t1 : t2);
+    fe_store(b + i, party == 0 ? t2 : party == 1 ? t0 : t1);
+}
+int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, uint64_t seed0, uint64_t seed1, int party, cozk_vec** out_a, cozk_vec** out_b) {
+    if (!out_a || !out_b) return COZK_ERR_INVALID_ARG;
+    *out_a = *out_b = nullptr;
+    int rc = cozk_guard(ctx, [&] { COZK_REQUIRE(ctx && v && v->kind == COZK_SCALAR_FR && party >= 0 && party < 3, "rep3_share_vec: bad argument"); });
+    if (rc != COZK_OK) return rc;
+    rc = cozk_vec_alloc(ctx, v->n, COZK_SCALAR_FR, out_a);
+    if (rc != COZK_OK) return rc;
+    rc = cozk_vec_alloc(ctx, v->n, COZK_SCALAR_FR, out_b);
+    if (rc != COZK_OK) {
+        cozk_vec_free(*out_a);
+        *out_a = nullptr;
+        return rc;
+    }
+    return cozk_guard(ctx, [&] {
+        if (v->n == 0) return;
+        k_rep3_share<<<(unsigned)((v->n + 255) / 256), 256, 0, ctx->stream>>>((const fe*)v->d, v->n, seed0, seed1, party, (fe*)(*out_a)->d, (fe*)(*out_b)->d);
+        HIP_TRY(hipGetLastError());
+    });
+}
+
 int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits) {
     return cozk_guard(ctx, [&] {
         COZK_REQUIRE(ctx && v, "vec_fill_random: bad argument");

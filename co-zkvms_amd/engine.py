@@ -190,6 +190,12 @@ class Vec:
             return mont_limbs_to_int(a)
         return [int(x) for x in a]
 
+    def rep3_share(self, seed0, seed1, party):
+        """Rep3 shares (a, b) of this secret vector for `party` (cozk_rep3_share_vec)"""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_rep3_share_vec(self.ctx.h, self.h, seed0, seed1, party, ctypes.byref(a), ctypes.byref(b)))
+        return Vec(self.ctx, a, L.SCALAR_FR), Vec(self.ctx, b, L.SCALAR_FR)
+
     def binop(self, op, other, base_field=False):
         out = Vec.alloc(self.ctx, len(self), L.SCALAR_FR)
         self.ctx.check(self.ctx._l.cozk_vec_binop(self.ctx.h, op, 1 if base_field else 0, self.h, other.h, out.h))

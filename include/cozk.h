@@ -85,6 +85,13 @@ void* cozk_vec_device_ptr(const cozk_vec* v);
  * the value to that many bits (e.g. 1 for 0/1 flags). */
 int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits);
 
+/* Rep3 sharing of a secret vector on the device -- the witness scatter (rep3::share_field_element,
+ * mpc-core/src/protocols/rep3/arithmetic.rs:21-33; jolt/vm/../witness.rs generate_poly_shares_rep3): t0 = stream(seed0),
+ * t1 = stream(seed1) (the generator of cozk_vec_fill_random), t2 = v - t0 - t1; returns `party`'s (a, b) =
+ * (t0, t2) / (t1, t0) / (t2, t1).  The dealer calls it once per party (or every party derives its own pair from
+ * shared seeds when v is public to the dealer only). */
+int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, uint64_t seed0, uint64_t seed1, int party,
+                        cozk_vec** out_a, cozk_vec** out_b);
 /* element-wise out[i] = a[i] (op) b[i] on 32-byte field elements: the local arithmetic of
  * mpc-types/src/protocols/additive/ops.rs (AdditivePrimeFieldShare is repr(transparent) over F).
  * base_field = 0: Fr (scalar field, what shares live in); 1: Fq (G1 coordinate field). */

@@ -150,3 +150,20 @@ def test_msm_repeated_bases_take_the_exception_path(cozk, ctx):
     flags = [rng.next() & 1 for _ in range(n)]
     got = B.msm(cozk.Vec.from_ints(ctx, flags, kind=cozk.SCALAR_U8))
     assert got == O.g1_mul(g, sum(flags) % O.R)
+
+
+def test_rep3_share_vec_matches_oracle_sharing(cozk, ctx):
+    """witness scatter on the device: party p's (a, b) of rep3::share_field_element with t0 = stream(seed0),
+    t1 = stream(seed1); the three a components open to the secret, and b is the previous party's a"""
+    n = 257
+    v = O.synthetic_fr(4040, n)
+    V = cozk.Vec.from_ints(ctx, v)
+    t0, t1 = O.synthetic_fr(51, n), O.synthetic_fr(52, n)
+    t2 = [(x - y - z) % O.R for x, y, z in zip(v, t0, t1)]
+    exp = [(t0, t2), (t1, t0), (t2, t1)]
+    got = []
+    for p in range(3):
+        a, b = V.rep3_share(51, 52, p)
+        got.append((a.to_ints(), b.to_ints()))
+        assert got[p] == exp[p]
+    assert [(x + y + z) % O.R for x, y, z in zip(got[0][0], got[1][0], got[2][0])] == v
