@@ -489,8 +489,8 @@ __global__ void __launch_bounds__(RT) k_layer_round_small(const fe* __restrict__
 // through a mailbox in fine-grained pinned memory: it publishes the three cubic sums of a round, spins (lane 0
 // only; the other waves sit at the barrier) until the host has posted the challenge, binds layer + eq tables,
 // and goes on -- a PCIe round trip (~3 us) per round instead of a launch.  After the last challenge it binds once
-// more and publishes the final claims.  Every wait is bounded by the wall clock (MB_TIMEOUT_TICKS of the 100 MHz
-// counter): a host that never answers makes the kernel raise `status` and return, so the grid always drains.
+// more and publishes the final claims.  Every wait is bounded by the wall clock (resident_timeout_s() seconds of the
+// 100 MHz counter): a host that never answers makes the kernel raise `status` and return, so the grid always drains.
 struct alignas(64) RoundMailbox {
     uint32_t cmd_seq;  // host -> device: challenge number k has been posted (k = 1, 2, ...)
     uint32_t abort;    // host -> device: give up
@@ -503,13 +503,23 @@ struct alignas(64) RoundMailbox {
     fe res[4];         // device -> host: cubic sums g(0), g(2), g(3); final: left.a, left.b, right.a, right.b
     unsigned long long dbg[8];  // device -> host: 100 MHz ticks spent waiting / binding / in the cubic sums / publishing
 };
-static constexpr long long MB_TIMEOUT_TICKS = 10ll * 100000000ll;  // 10 s
+static constexpr long long MB_TICKS_PER_S = 100000000ll;  // wall_clock64() runs at 100 MHz
+// watchdog of the resident kernel, seconds (COZK_RESIDENT_TIMEOUT_S, default 10, 1..600): raise it when the round
+// callback can legitimately take longer (a coordinator across a slow link)
+static int resident_timeout_s() {
+    static const int v = [] {
+        const char* e = getenv("COZK_RESIDENT_TIMEOUT_S");
+        int t = e ? atoi(e) : 10;
+        return t < 1 ? 1 : (t > 600 ? 600 : t);
+    }();
+    return v;
+}
 static constexpr size_t ROUND_PERSIST_MAX = 2048;
 
 template <int NC>
 __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0, fe* la1, fe* lb1, int lcur, size_t len, fe* e1_0, fe* e1_1,
                                                              int c1, size_t E1_len, fe* e2_0, fe* e2_1, int c2, size_t E2_len, int nrounds,
-                                                             int bind_first, fe r_first, RoundMailbox* mb) {
+                                                             int bind_first, fe r_first, RoundMailbox* mb, long long timeout_ticks) {
     __shared__ fe sh16[16];
     __shared__ fe sh_r;
     __shared__ int sh_ok;
@@ -535,7 +545,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
                         __hip_atomic_store(&mb->status, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    if (wall_clock64() - t0 > MB_TIMEOUT_TICKS) {
+                    if (wall_clock64() - t0 > timeout_ticks) {
                         ok = 0;
                         __hip_atomic_store(&mb->status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
@@ -2058,12 +2068,13 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
         memset(mb, 0, sizeof *mb);
         std::atomic_thread_fence(std::memory_order_seq_cst);
         fe r_first = have_r ? fe_from_u64x4(rr) : Fr::zero();
+        const long long ticks = (long long)resident_timeout_s() * MB_TICKS_PER_S;
         if (l->mode == COZK_MODE_REP3)
             k_layer_rounds_persistent<2><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], l->buf[0][1], l->buf[1][0], l->buf[1][1], l->cur, l->len, e->E1[0], e->E1[1],
-                                                                   e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb);
+                                                                   e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
         else
             k_layer_rounds_persistent<1><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], nullptr, l->buf[1][0], nullptr, l->cur, l->len, e->E1[0], e->E1[1], e->c1,
-                                                                   e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb);
+                                                                   e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
         HIP_TRY(hipGetLastError());
         volatile uint32_t* res_seq = &mb->res_seq;
         volatile uint32_t* status = &mb->status;
@@ -2079,7 +2090,7 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
             while (*res_seq != want) {
                 if (*status) give_up("layer_prove_rounds: the resident kernel gave up waiting for the host");
                 __builtin_ia32_pause();
-                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(15))
+                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(resident_timeout_s() + 5))
                     give_up("layer_prove_rounds: no result from the resident kernel");
             }
             std::atomic_thread_fence(std::memory_order_acquire);

@@ -63,7 +63,7 @@ const char* cozk_last_error(cozk_ctx* ctx);
  * waits for the host's challenge, kernels of other streams that the driver mapped to the same hardware queue
  * cannot start.  That is harmless for independent provers, but provers that need EACH OTHER's round messages to
  * make progress (several parties of one protocol run driven from one process on one GPU) could then wait for
- * each other forever (the kernel's 10 s watchdog turns that into an error).  Disable it for such contexts;
+ * each other forever (the kernel's watchdog -- 10 s, COZK_RESIDENT_TIMEOUT_S -- turns that into an error).  Disable it for such contexts;
  * one party per process -- the reference's deployment -- is safe.  Default: enabled. */
 int cozk_ctx_set_resident_rounds(cozk_ctx* ctx, int enable);
 int cozk_ctx_synchronize(cozk_ctx* ctx);
