@@ -19,6 +19,19 @@ MODE_PLAIN, MODE_REP3 = 1, 2
 OP_ADD, OP_SUB, OP_MUL = 0, 1, 2
 
 
+PRF_KEY_BYTES = 32
+
+
+def prf_key(k):
+    """a 32-byte ChaCha12 PRF key for the ABI: bytes of length 32, or None (all-zero key, unmasked calls only)"""
+    if k is None:
+        return None
+    k = bytes(k)
+    if len(k) != PRF_KEY_BYTES:
+        raise ValueError("PRF keys are %d bytes" % PRF_KEY_BYTES)
+    return k
+
+
 class CozkError(RuntimeError):
     def __init__(self, code, msg):
         super().__init__(f"cozk error {code}: {msg}")
@@ -104,13 +117,14 @@ SIGNATURES = {
     "cozk_layer_bind": (_i, [_vp, _vp, _vp]),
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_ctx_set_resident_rounds": (_i, [_vp, _i]),
-    "cozk_rep3_share_vec": (_i, [_vp, _vp, _u64, _u64, _i, _pp, _pp]),
+    "cozk_rep3_share_vec": (_i, [_vp, _vp, ctypes.c_char_p, ctypes.c_char_p, _u64, _i, _pp, _pp]),
+    "cozk_vec_fill_prf": (_i, [_vp, _vp, ctypes.c_char_p, _u64]),
     "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cozk_fingerprint_leaves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _sz, _sz]),
     "cozk_layer_prove_rounds": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp]),
     "cozk_layer_final_claims": (_i, [_vp, _vp, _vp]),
-    "cozk_layer_output_local": (_i, [_vp, _vp, _i, _u64, _u64, _u64, _pp]),
-    "cozk_rep3_mul_vec_local": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _u64, _u64, _u64, _pp]),
+    "cozk_layer_output_local": (_i, [_vp, _vp, _i, ctypes.c_char_p, ctypes.c_char_p, _u64, _pp]),
+    "cozk_rep3_mul_vec_local": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, ctypes.c_char_p, ctypes.c_char_p, _u64, _pp]),
     "cozk_layer_claimed_outputs": (_i, [_vp, _vp, _vp]),
     "cozk_spliteq_new": (_i, [_vp, _vp, _i, _pp]),
     "cozk_spliteq_free": (_i, [_vp]),
@@ -119,6 +133,8 @@ SIGNATURES = {
     "cozk_prof_enable": (_i, [_vp, _i]),
     "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
     "cozk_layer_as_poly": (_i, [_vp, _vp, _pp]),
+    "cozk_wire_g1_encode": (_i, [_vp, _i, _vp]),
+    "cozk_wire_g1_decode": (_i, [_vp, _vp, ctypes.POINTER(_i)]),
     "cozk_bench_montmul": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(ctypes.c_double)]),
 }
 

@@ -1,6 +1,7 @@
 // libcozk C ABI: context, device vectors, synthetic data, micro-benchmarks.
 #include "common.hpp"
 #include "fq9.cuh"
+#include "prf.cuh"
 
 // ------------------------------------------------------------------ synthetic data
 static __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
@@ -11,8 +12,8 @@ static __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
     return z ^ (z >> 31);
 }
 
-// element i draws from its own SplitMix64 stream seeded with seed + i * 0xD1342543DE82EF95
-// (oracle/pyref.py `synthetic_fr` restates this).  FR: rejection-sample a canonical value < r
+// SYNTHETIC DATA ONLY (never secret randomness -- that is prf.cuh): element i draws from its own SplitMix64 stream
+// seeded with seed + i * 0xD1342543DE82EF95 (oracle/pyref.py `synthetic_fr` restates this).  FR: rejection-sample a canonical value < r
 // (top word masked to 62 bits), optionally masked to max_bits, stored in Montgomery form.
 __global__ void k_fill_random_fr(fe* out, size_t n, uint64_t seed, int max_bits) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -167,10 +168,11 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
     return COZK_OK;
 }
 
-// see cozk.h: the resident round kernel must not be used by provers whose progress depends on each other's GPU work
+// see cozk.h: the resident round kernel must not be used by provers whose progress depends on each other's GPU work;
+// enable > 0 on, 0 off, < 0 back to the automatic default (on only while the context is alone on its device)
 int cozk_ctx_set_resident_rounds(cozk_ctx* ctx, int enable) {
     if (!ctx) return COZK_ERR_INVALID_ARG;
-    ctx->resident_rounds = enable != 0;
+    ctx->resident_rounds = enable > 0 ? 1 : (enable == 0 ? 0 : -1);
     return COZK_OK;
 }
 
@@ -228,35 +230,37 @@ size_t cozk_vec_len(const cozk_vec* v) { return v ? v->n : 0; }
 void* cozk_vec_device_ptr(const cozk_vec* v) { return v ? v->d : nullptr; }
 
 // Rep3 sharing of a secret vector on the device (rep3::share_field_element, mpc-core/src/protocols/rep3/arithmetic.rs:
-// 21-33; the witness scatter of jolt/vm/*/witness.rs generate_poly_shares_rep3): t0 = stream(seed0), t1 = stream(seed1),
-// t2 = v - t0 - t1; party 0 holds (t0, t2), party 1 (t1, t0), party 2 (t2, t1).  One fused pass, no temporaries.
+// 21-33; the witness scatter of jolt/vm/*/witness.rs generate_poly_shares_rep3): t0 = PRF(key0, .), t1 = PRF(key1, .)
+// (ChaCha12, prf.cuh), t2 = v - t0 - t1; party 0 holds (t0, t2), party 1 (t1, t0), party 2 (t2, t1).  One fused pass.
 // (The reference's generate_poly_shares_rep3 repeats ONE random element over the whole vector, SURVEY 9: not copied.)
-static __device__ __forceinline__ fe stream_fr(uint64_t seed, size_t i) {
-    uint64_t s = seed + (uint64_t)i * 0xD1342543DE82EF95ull;
-    fe v;
-    for (;;) {
-        uint64_t w0 = splitmix_next(s), w1 = splitmix_next(s), w2 = splitmix_next(s);
-        uint64_t w3 = splitmix_next(s) & ((1ull << 62) - 1ull);
-        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
-        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
-        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
-        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
-        if (!Fr::geq_mod(v)) break;
-    }
-    return Fr::to_mont(v);
-}
-__global__ void k_rep3_share(const fe* __restrict__ v, size_t n, uint64_t seed0, uint64_t seed1, int party, fe* __restrict__ a, fe* __restrict__ b) {
+__global__ void __launch_bounds__(256) k_rep3_share(const fe* __restrict__ v, size_t n, prf_key key0, prf_key key1, uint64_t ctr, int party,
+                                                    fe* __restrict__ a, fe* __restrict__ b) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    fe t0 = stream_fr(seed0, i), t1 = stream_fr(seed1, i);
+    fe t0 = prf_fr(key0, ctr + i), t1 = prf_fr(key1, ctr + i);
     fe t2 = Fr::sub(Fr::sub(fe_load(v + i), t0), t1);
     fe_store(a + i, party == 0 ? t0 : party == 1 ? t1 : t2);
     fe_store(b + i, party == 0 ? t2 : party == 1 ? t0 : t1);
 }
-int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, uint64_t seed0, uint64_t seed1, int party, cozk_vec** out_a, cozk_vec** out_b) {
+__global__ void __launch_bounds__(256) k_fill_prf(fe* __restrict__ out, size_t n, prf_key key, uint64_t ctr) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) fe_store(out + i, prf_fr(key, ctr + i));
+}
+int cozk_vec_fill_prf(cozk_ctx* ctx, cozk_vec* v, const uint8_t key[COZK_PRF_KEY_BYTES], uint64_t counter) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && v && key && v->kind == COZK_SCALAR_FR, "vec_fill_prf: bad argument");
+        if (v->n == 0) return;
+        k_fill_prf<<<(unsigned)((v->n + 255) / 256), 256, 0, ctx->stream>>>((fe*)v->d, v->n, prf_key_from_bytes(key), counter);
+        HIP_TRY(hipGetLastError());
+    });
+}
+int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES], const uint8_t key1[COZK_PRF_KEY_BYTES],
+                        uint64_t counter, int party, cozk_vec** out_a, cozk_vec** out_b) {
     if (!out_a || !out_b) return COZK_ERR_INVALID_ARG;
     *out_a = *out_b = nullptr;
-    int rc = cozk_guard(ctx, [&] { COZK_REQUIRE(ctx && v && v->kind == COZK_SCALAR_FR && party >= 0 && party < 3, "rep3_share_vec: bad argument"); });
+    int rc = cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && v && key0 && key1 && v->kind == COZK_SCALAR_FR && party >= 0 && party < 3, "rep3_share_vec: bad argument");
+    });
     if (rc != COZK_OK) return rc;
     rc = cozk_vec_alloc(ctx, v->n, COZK_SCALAR_FR, out_a);
     if (rc != COZK_OK) return rc;
@@ -268,7 +272,8 @@ int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, uint64_t seed0, uint64
     }
     return cozk_guard(ctx, [&] {
         if (v->n == 0) return;
-        k_rep3_share<<<(unsigned)((v->n + 255) / 256), 256, 0, ctx->stream>>>((const fe*)v->d, v->n, seed0, seed1, party, (fe*)(*out_a)->d, (fe*)(*out_b)->d);
+        k_rep3_share<<<(unsigned)((v->n + 255) / 256), 256, 0, ctx->stream>>>((const fe*)v->d, v->n, prf_key_from_bytes(key0), prf_key_from_bytes(key1),
+                                                                              counter, party, (fe*)(*out_a)->d, (fe*)(*out_b)->d);
         HIP_TRY(hipGetLastError());
     });
 }

@@ -157,7 +157,7 @@ struct cozk_ctx {
     DevBuf scratch2;
     void* pinned = nullptr;  // pinned host staging for small D2H results
     size_t pinned_cap = 0;
-    bool resident_rounds = true;     // cozk_ctx_set_resident_rounds
+    int resident_rounds = -1;        // cozk_ctx_set_resident_rounds: 1 on, 0 off, -1 automatic (ctx_resident_rounds_enabled)
     void* mailbox = nullptr;         // fine-grained pinned host memory shared with the resident round kernel
     uint32_t* round_flag = nullptr;  // pinned word a stream write bumps behind each round's finishing kernel
     uint32_t round_seq = 0;
@@ -211,6 +211,17 @@ static inline void trim_current_pool() {
 static inline bool ctx_is_live(cozk_ctx* ctx) {
     std::lock_guard<std::mutex> lk(g_ctx_mu);
     return g_live_ctx.count(ctx) != 0;
+}
+// Resident round kernels (cozk_layer_prove_rounds) are safe only for a context whose progress does not depend on GPU
+// work of another context that the driver may have mapped to the same hardware queue.  libcozk cannot see such
+// dependencies, so unless the host said otherwise (cozk_ctx_set_resident_rounds) the kernel is used only while this is
+// the ONE live context on its device in this process -- the reference's deployment, one party per process.
+static inline bool ctx_resident_rounds_enabled(cozk_ctx* ctx) {
+    if (ctx->resident_rounds >= 0) return ctx->resident_rounds != 0;
+    std::lock_guard<std::mutex> lk(g_ctx_mu);
+    int same_device = 0;
+    for (cozk_ctx* c : g_live_ctx) same_device += c->device == ctx->device;
+    return same_device <= 1;
 }
 static inline void* ctx_dev_alloc(cozk_ctx* ctx, size_t bytes) {
     static const bool no_pool = getenv("COZK_NO_POOL") != nullptr;  // diagnostic: plain hipMalloc / hipFree

@@ -137,28 +137,22 @@ static VecH vec_binop(cozk_ctx* ctx, int op, const VecH& a, const VecH& b) {
     return h;
 }
 
-// share components of the secret vector stream(seed): P0 = (t0, t2), P1 = (t1, t0), P2 = (t2, t1)
-// with t0 = stream(seed+1), t1 = stream(seed+2), t2 = v - t0 - t1 (arithmetic.rs:21-33)
+// share components of the synthetic secret vector stream(seed) through the engine's witness scatter
+// (cozk_rep3_share_vec: t0 = PRF(k0, i), t1 = PRF(k1, i), t2 = v - t0 - t1; P0 = (t0, t2), P1 = (t1, t0), P2 = (t2, t1);
+// arithmetic.rs:21-33) with the harness keys (seed, 101) and (seed, 102)
 static void make_share_vectors(cozk_ctx* ctx, size_t n, uint64_t seed, int party, int mode, VecH& a, VecH& b) {
     if (mode == COZK_MODE_PLAIN) {
         a = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
         return;
     }
     VecH v = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
-    VecH t0 = make_vec_random(ctx, n, COZK_SCALAR_FR, seed + 1, 0);
-    VecH t1 = make_vec_random(ctx, n, COZK_SCALAR_FR, seed + 2, 0);
-    VecH d = vec_binop(ctx, COZK_OP_SUB, v, t0);
-    VecH t2 = vec_binop(ctx, COZK_OP_SUB, d, t1);
-    if (party == 0) {
-        a = std::move(t0);
-        b = std::move(t2);
-    } else if (party == 1) {
-        a = std::move(t1);
-        b = std::move(t0);
-    } else {
-        a = std::move(t2);
-        b = std::move(t1);
-    }
+    uint8_t k0[COZK_PRF_KEY_BYTES], k1[COZK_PRF_KEY_BYTES];
+    harness_prf_key(seed, 101, k0);
+    harness_prf_key(seed, 102, k1);
+    cozk_vec *sa = nullptr, *sb = nullptr;
+    rc_check(cozk_rep3_share_vec(ctx, v.h, k0, k1, 0, party, &sa, &sb), ctx, "rep3_share_vec");
+    a = VecH(sa);
+    b = VecH(sb);
 }
 
 static void setup_party(cozk_harness* h, PartyState& ps) {
@@ -253,8 +247,8 @@ static void worker_main(cozk_harness* h, PartyState& ps, StarNetWorker* star, Ri
     env.party = ps.party;
     env.star = star;
     env.ring = ring;
-    env.seed_self = c.seed + 900000ull + (uint64_t)ps.party;
-    env.seed_prev = c.seed + 900000ull + (uint64_t)((ps.party + 2) % 3);
+    harness_prf_key(c.seed, (uint64_t)ps.party, env.key_self);
+    harness_prf_key(c.seed, (uint64_t)((ps.party + 2) % 3), env.key_prev);
     HIP_TRY(hipSetDevice(ps.ctx->device));
     double t_start = now_ms();
     // ---- 1. commit (Rep3JoltPolynomials::commit, jolt/vm/jolt/witness.rs:304-382): every party MSMs
@@ -660,9 +654,10 @@ int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out) {
                 int rc = cozk_ctx_create(dev, &ps.ctx);
                 if (rc != COZK_OK) throw CozkError(rc, "harness: cannot create a context (no HIP device?)");
                 ps.own_ctx = true;
-                // several participants driven from this one process wait for each other's round messages: no
-                // resident round kernels (cozk_ctx_set_resident_rounds)
-                if (h->nparties * W > 1) cozk_ctx_set_resident_rounds(ps.ctx, 0);
+                // several participants driven from this one process wait for each other's round messages: no resident
+                // round kernels (cozk_ctx_set_resident_rounds); a lone participant depends on nobody's GPU work, so it
+                // keeps them even when the host has other, unrelated contexts open on the device
+                cozk_ctx_set_resident_rounds(ps.ctx, h->nparties * W > 1 ? 0 : 1);
                 HIP_TRY(hipSetDevice(ps.ctx->device));
                 if (W > 1) setup_participant_split(h, ps, w);
                 else setup_party(h, ps);
@@ -959,6 +954,35 @@ cozk_ctx* cozk_harness_ctx(cozk_harness* h, int party) {
 
 }  // extern "C"
 
+// --------------------------------------------------------------------------- wire format (host only)
+extern "C" {
+int cozk_wire_g1_encode(const uint64_t xy[8], int infinity, uint8_t out[64]) {
+    if (!xy || !out) return COZK_ERR_INVALID_ARG;
+    try {
+        Writer w;
+        w.g1(abi_to_g1(xy, infinity));
+        memcpy(out, w.b.data(), 64);
+        return COZK_OK;
+    } catch (const std::exception&) {
+        return COZK_ERR_INTERNAL;
+    }
+}
+int cozk_wire_g1_decode(const uint8_t in[64], uint64_t xy[8], int* infinity) {
+    if (!in || !xy || !infinity) return COZK_ERR_INVALID_ARG;
+    try {
+        Bytes b(in, in + 64);
+        Reader rd(b);
+        g1_affine p = rd.g1();
+        *infinity = G1::is_inf(p) ? 1 : 0;
+        fe_to_u64x4(p.x, xy);
+        fe_to_u64x4(p.y, xy + 4);
+        return COZK_OK;
+    } catch (const std::exception&) {
+        return COZK_ERR_INVALID_ARG;
+    }
+}
+}  // extern "C"
+
 // --------------------------------------------------------------------------- worker drivers over host nets
 // The C++ round loops of csrc/host/prover.hpp with the host's own transport plugged in (cozk_star_net /
 // cozk_ring_net): what a Rust host calls when it wants the loop, not just the per-round kernels.
@@ -969,8 +993,7 @@ static WorkerEnv make_env(cozk_ctx* ctx, const cozk_worker_params* wp, StarNetWo
     env.party = wp->party;
     env.star = star;
     env.ring = ring;
-    env.seed_self = wp->seed_self;
-    env.seed_prev = wp->seed_prev;
+    env.set_keys(wp->key_self, wp->key_prev);
     env.mask_ctr = wp->mask_counter;
     return env;
 }

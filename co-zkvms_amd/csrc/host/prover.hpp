@@ -15,7 +15,10 @@
 #include <chrono>
 #include <memory>
 
+#include <string.h>
+
 #include "net.hpp"
+#include "../prf.cuh"
 
 namespace cozk {
 
@@ -96,9 +99,13 @@ struct WorkerEnv {
     int party;  // PartyID 0..2 (0 for the plain prover)
     StarNetWorker* star;
     RingNet* ring;            // null for the plain prover
-    uint64_t seed_self = 0;   // PRF key shared with the next party
-    uint64_t seed_prev = 0;   // PRF key shared with the previous party
+    uint8_t key_self[COZK_PRF_KEY_BYTES] = {0};  // 32-byte ChaCha12 PRF key shared with the next party (prf.cuh)
+    uint8_t key_prev[COZK_PRF_KEY_BYTES] = {0};  // ... with the previous party
     uint64_t mask_ctr = 0;    // zero-sharing counter (advances identically on all parties)
+    void set_keys(const uint8_t* self_key, const uint8_t* prev_key) {
+        memcpy(key_self, self_key, COZK_PRF_KEY_BYTES);
+        memcpy(key_prev, prev_key, COZK_PRF_KEY_BYTES);
+    }
 
     // additive::promote_to_trivial_share(value, id) (mpc-core/src/protocols/additive.rs:62-64)
     fe additive_trivial(const fe& v) const { return party == 0 ? v : Fr::zero(); }
@@ -115,6 +122,21 @@ struct WorkerEnv {
         return Fr::mul(Fr::add(s.a, s.b), fr_two_inv());
     }
 };
+
+// Keys of the in-process HARNESSES only: a real host hands libcozk the 32-byte seeds its parties exchanged (from its
+// CryptoRng); the synthetic runs expand (run seed, key index) to 32 bytes so that every party derives the same pairwise
+// keys without a key exchange.  Key `idx` is the one party idx shares with party idx + 1.
+static inline void harness_prf_key(uint64_t seed, uint64_t idx, uint8_t out[COZK_PRF_KEY_BYTES]) {
+    uint64_t s = seed ^ (0xC0DEC0DEull + idx * 0x9E3779B97F4A7C15ull);
+    for (int i = 0; i < 4; i++) {
+        s += 0x9E3779B97F4A7C15ull;
+        uint64_t z = s;
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        for (int b = 0; b < 8; b++) out[8 * i + b] = (uint8_t)(z >> (8 * b));
+    }
+}
 
 // ================================================================= cubic sumcheck over one GKR layer
 struct SumcheckResult {
@@ -256,7 +278,7 @@ struct Rep3BatchedDenseGrandProduct {
             cozk_layer* prev = gp.layers[i].h;
             size_t n_out = (cozk_layer_len(prev) + 1) / 2;
             cozk_vec* ca = nullptr;
-            rc_check(cozk_layer_output_local(env.ctx, prev, env.mode == COZK_MODE_REP3 ? 1 : 0, env.seed_self, env.seed_prev,
+            rc_check(cozk_layer_output_local(env.ctx, prev, env.mode == COZK_MODE_REP3 ? 1 : 0, env.key_self, env.key_prev,
                                              env.mask_ctr, &ca),
                      env.ctx, "layer_output_local");
             VecH va(ca);
@@ -920,7 +942,7 @@ static ArbitraryResult prove_arbitrary_worker(WorkerEnv& env, const fe& claim, i
 // ================================================================= co-noir-spartan sumcheck workers
 // rep3_first_sumcheck_worker (co-noir-spartan/co-spartan/src/worker.rs:593-639): per round send the 4
 // evaluations (+ additive zero-mask, co-spartan/src/sumcheck.rs:271-273), receive r, fix_variables.
-// The mask stream is PRF(seed_self) - PRF(seed_prev) (get_mask_scalar_additive, mpc-core/src/protocols/additive.rs:44-50);
+// The mask stream is PRF(key_self) - PRF(key_prev) (get_mask_scalar_additive, mpc-core/src/protocols/additive.rs:44-50);
 // returns the point; `finals` = (za, zb, zc share_0[0], eq[0]) as sent at the end.
 static fe spartan_mask_additive(WorkerEnv& env);
 static std::vector<fe> rep3_first_sumcheck_worker(WorkerEnv& env, cozk_poly* za, cozk_poly* zb, cozk_poly* zc, cozk_poly* eq, std::vector<fe>& finals) {
@@ -997,30 +1019,10 @@ static std::vector<fe> rep3_second_sumcheck_worker(WorkerEnv& env, cozk_poly* z,
     return point;
 }
 
-// host-side PRF for the tiny per-round masks: the same SplitMix64 stream as the device PRF (poly.hip prf_fr)
-static inline uint64_t host_sm_next(uint64_t& s) {
-    s += 0x9E3779B97F4A7C15ull;
-    uint64_t z = s;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-static inline fe host_prf_fr(uint64_t seed, uint64_t j) {
-    uint64_t s = seed + j * 0xD1342543DE82EF95ull;
-    fe v;
-    for (;;) {
-        uint64_t w0 = host_sm_next(s), w1 = host_sm_next(s), w2 = host_sm_next(s), w3 = host_sm_next(s) & ((1ull << 62) - 1ull);
-        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
-        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
-        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
-        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
-        if (!Fr::geq_mod(v)) break;
-    }
-    return Fr::to_mont(v);
-}
+// the tiny per-round masks are made on the host with the same keyed ChaCha12 PRF as the device masks (prf.cuh)
 static fe spartan_mask_additive(WorkerEnv& env) {
     if (env.mode != COZK_MODE_REP3) return Fr::zero();  // a single party has nothing to hide from itself
-    fe m = Fr::sub(host_prf_fr(env.seed_self, env.mask_ctr), host_prf_fr(env.seed_prev, env.mask_ctr));
+    fe m = Fr::sub(prf_fr(prf_key_from_bytes(env.key_self), env.mask_ctr), prf_fr(prf_key_from_bytes(env.key_prev), env.mask_ctr));
     env.mask_ctr++;
     return m;
 }

@@ -162,14 +162,15 @@ static void spartan_setup_party(cozk_spartan* h, SpartanParty& ps, const std::ve
     if (c.mode == COZK_MODE_PLAIN) {
         ps.z = plain_poly_from(ctx, zv);
     } else {
-        VecH t0 = make_vec_random(ctx, n, COZK_SCALAR_FR, c.seed + 1001ull, 0);
-        VecH t1 = make_vec_random(ctx, n, COZK_SCALAR_FR, c.seed + 1002ull, 0);
-        VecH d = vec_binop(ctx, COZK_OP_SUB, zv, t0);
-        VecH t2 = vec_binop(ctx, COZK_OP_SUB, d, t1);
-        const VecH* a = ps.party == 0 ? &t0 : ps.party == 1 ? &t1 : &t2;
-        const VecH* b = ps.party == 0 ? &t2 : ps.party == 1 ? &t0 : &t1;
+        // the witness scatter of the engine: t0 = PRF(k0, i), t1 = PRF(k1, i) (cozk_rep3_share_vec, ChaCha12)
+        uint8_t k0[COZK_PRF_KEY_BYTES], k1[COZK_PRF_KEY_BYTES];
+        harness_prf_key(c.seed + 1000ull, 101, k0);
+        harness_prf_key(c.seed + 1000ull, 102, k1);
+        cozk_vec *sa = nullptr, *sb = nullptr;
+        rc_check(cozk_rep3_share_vec(ctx, zv.h, k0, k1, 0, ps.party, &sa, &sb), ctx, "rep3_share_vec");
+        VecH a(sa), b(sb);
         cozk_poly* p = nullptr;
-        rc_check(cozk_poly_create(ctx, COZK_MODE_REP3, a->h, b->h, &p), ctx, "poly_create");
+        rc_check(cozk_poly_create(ctx, COZK_MODE_REP3, a.h, b.h, &p), ctx, "poly_create");
         ps.z = PolyH(p);
     }
     // CSR by row: three entries per row
@@ -212,8 +213,8 @@ static void spartan_worker_main(cozk_spartan* h, SpartanParty& ps, StarNetWorker
     env.party = ps.party;
     env.star = star;
     env.ring = nullptr;  // neither sumcheck multiplies two secrets across parties: no reshare on this path
-    env.seed_self = c.seed + 900000ull + (uint64_t)ps.party;
-    env.seed_prev = c.seed + 900000ull + (uint64_t)((ps.party + 2) % 3);
+    harness_prf_key(c.seed, (uint64_t)ps.party, env.key_self);
+    harness_prf_key(c.seed, (uint64_t)((ps.party + 2) % 3), env.key_prev);
     HIP_TRY(hipSetDevice(ctx->device));
     double t0 = now_ms();
     // ---- zero_round (worker.rs:153-182)

@@ -92,8 +92,8 @@ static void worker_main_split(cozk_harness* h, PartyState& ps, int worker, StarN
     se.env.party = ps.party;
     se.env.star = star;
     se.env.ring = ring;
-    se.env.seed_self = c.seed + 900000ull + (uint64_t)ps.party + 16ull * (uint64_t)worker;
-    se.env.seed_prev = c.seed + 900000ull + (uint64_t)((ps.party + 2) % 3) + 16ull * (uint64_t)worker;
+    harness_prf_key(c.seed, (uint64_t)ps.party + 16ull * (uint64_t)worker, se.env.key_self);
+    harness_prf_key(c.seed, (uint64_t)((ps.party + 2) % 3) + 16ull * (uint64_t)worker, se.env.key_prev);
     se.worker = worker;
     se.k = c.log_workers;
     WorkerEnv& env = se.env;

@@ -3,7 +3,11 @@
 // Wire = ark-serialize *uncompressed* encoding, as the reference's transport uses
 // (mpc-net/src/rep3/quic/worker.rs:187-219): Fr = 32-byte little-endian canonical integer,
 // Vec<T> = u64 LE length prefix + elements, tuples = concatenation, usize = u64 LE,
-// G1Affine = x || y (32 B LE each) with the infinity flag in bit 6 of the last byte.
+// G1Affine = x || y (32 B LE each) with ark-ec's SWFlags in the two spare top bits of the last byte: bit 6 = point at
+// infinity (x = y = 0), bit 7 = "y is negative", i.e. y > -y as integers (short_weierstrass serialize_with_mode passes
+// `to_flags()` to y.serialize_with_flags also when uncompressed; from upstream knowledge of ark-ec 0.5 -- the reference
+// holds no serialized point to pin it, see tests/golden/wire_format.json).  Readers ignore bit 7 and validate like
+// arkworks' Validate::Yes: canonical coordinates, on the curve (BN254 G1 has cofactor 1: no subgroup check needed).
 #pragma once
 #include <string.h>
 
@@ -36,11 +40,20 @@ struct Writer {
             b.push_back(0x40);
             return;
         }
-        fe x = Fq::from_mont(p.x), y = Fq::from_mont(p.y);
+        fe x = Fq::from_mont(p.x), y = Fq::from_mont(p.y), ny = Fq::from_mont(Fq::neg(p.y));
         for (int i = 0; i < 8; i++)
             for (int k = 0; k < 4; k++) b.push_back((uint8_t)(x.l[i] >> (8 * k)));
         for (int i = 0; i < 8; i++)
             for (int k = 0; k < 4; k++) b.push_back((uint8_t)(y.l[i] >> (8 * k)));
+        // SWFlags::from_y_coordinate: YIsNegative (bit 7) iff y > -y
+        bool neg = false;
+        for (int i = 7; i >= 0; i--) {
+            if (y.l[i] != ny.l[i]) {
+                neg = y.l[i] > ny.l[i];
+                break;
+            }
+        }
+        if (neg) b.back() |= 0x80;
     }
     void vec_g1(const std::vector<g1_affine>& v) {
         u64(v.size());
@@ -70,9 +83,13 @@ struct Reader {
         if (Fr::geq_mod(c)) throw CozkError(COZK_ERR_INTERNAL, "wire: non-canonical field element");
         return Fr::to_mont(c);
     }
+    // a length prefix is checked against what the message still holds BEFORE it is multiplied (no overflow)
+    void need_elems(uint64_t n, size_t elem) const {
+        if (n > (uint64_t)(end - p) / elem) throw CozkError(COZK_ERR_INTERNAL, "wire: truncated message");
+    }
     std::vector<fe> vec_fr() {
         uint64_t n = u64();
-        need(n * 32);
+        need_elems(n, 32);
         std::vector<fe> v(n);
         for (auto& x : v) x = fr();
         return v;
@@ -80,25 +97,33 @@ struct Reader {
     g1_affine g1() {
         need(64);
         g1_affine a;
-        if (p[63] & 0x40) {
-            a.x = Fq::zero();
-            a.y = Fq::zero();
-            p += 64;
-            return a;
-        }
         fe x, y;
         for (int i = 0; i < 8; i++) {
             x.l[i] = (uint32_t)p[4 * i] | ((uint32_t)p[4 * i + 1] << 8) | ((uint32_t)p[4 * i + 2] << 16) | ((uint32_t)p[4 * i + 3] << 24);
             y.l[i] = (uint32_t)p[32 + 4 * i] | ((uint32_t)p[33 + 4 * i] << 8) | ((uint32_t)p[34 + 4 * i] << 16) | ((uint32_t)p[35 + 4 * i] << 24);
         }
+        const uint8_t flags = p[63] & 0xC0;
+        y.l[7] &= 0x3fffffffu;  // the two flag bits are not part of y
         p += 64;
+        // what arkworks' deserialize (Validate::Yes) rejects is rejected here too: a peer's bytes are not trusted
+        if (flags == 0xC0) throw CozkError(COZK_ERR_INTERNAL, "wire: invalid point flags");
+        if (Fq::geq_mod(x) || Fq::geq_mod(y)) throw CozkError(COZK_ERR_INTERNAL, "wire: non-canonical point coordinate");
+        if (flags & 0x40) {
+            if (!Fq::is_zero(x) || !Fq::is_zero(y)) throw CozkError(COZK_ERR_INTERNAL, "wire: point at infinity with non-zero coordinates");
+            a.x = Fq::zero();
+            a.y = Fq::zero();
+            return a;
+        }
         a.x = Fq::to_mont(x);
         a.y = Fq::to_mont(y);
+        // y^2 = x^3 + 3
+        fe rhs = Fq::add(Fq::mul(Fq::sqr(a.x), a.x), Fq::from_u64(3));
+        if (!Fq::eq(Fq::sqr(a.y), rhs)) throw CozkError(COZK_ERR_INTERNAL, "wire: point is not on the curve");
         return a;
     }
     std::vector<g1_affine> vec_g1() {
         uint64_t n = u64();
-        need(n * 64);
+        need_elems(n, 64);
         std::vector<g1_affine> v(n);
         for (auto& x : v) x = g1();
         return v;
@@ -206,9 +231,14 @@ struct Transcript {
         absorb(w.b.data(), w.b.size());
     }
     void append_point(const g1_affine& p) {
+        // raw x || y without serialization flags (jolt's append_point hashes the two coordinates; zeros for infinity)
         Writer w;
-        if (G1::is_inf(p)) w.b.assign(64, 0);
-        else w.g1(p);
+        if (G1::is_inf(p)) {
+            w.b.assign(64, 0);
+        } else {
+            w.g1(p);
+            w.b.back() &= 0x3f;
+        }
         absorb(w.b.data(), w.b.size());
     }
     fe challenge_scalar() {

@@ -11,6 +11,7 @@
 #include <chrono>
 #include <string.h>
 #include "poly.cuh"
+#include "prf.cuh"
 
 static constexpr int PT = 256;      // threads per block
 static constexpr int MAXBLK = 2048; // grid cap for reducing kernels (>= 8 blocks per CU)
@@ -507,12 +508,9 @@ static constexpr long long MB_TICKS_PER_S = 100000000ll;  // wall_clock64() runs
 // watchdog of the resident kernel, seconds (COZK_RESIDENT_TIMEOUT_S, default 10, 1..600): raise it when the round
 // callback can legitimately take longer (a coordinator across a slow link)
 static int resident_timeout_s() {
-    static const int v = [] {
-        const char* e = getenv("COZK_RESIDENT_TIMEOUT_S");
-        int t = e ? atoi(e) : 10;
-        return t < 1 ? 1 : (t > 600 ? 600 : t);
-    }();
-    return v;
+    const char* e = getenv("COZK_RESIDENT_TIMEOUT_S");  // read per call (a handful of times per layer): hosts and tests may change it
+    int t = e ? atoi(e) : 10;
+    return t < 1 ? 1 : (t > 600 ? 600 : t);
 }
 static constexpr size_t ROUND_PERSIST_MAX = 2048;
 
@@ -699,41 +697,18 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
     }
 }
 
-static __device__ __forceinline__ uint64_t sm_next(uint64_t& s) {
-    s += 0x9E3779B97F4A7C15ull;
-    uint64_t z = s;
-    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-    return z ^ (z >> 31);
-}
-// PRF(seed, j): canonical value < r from the stream seeded with seed + j * 0xD1342543DE82EF95,
-// returned in Montgomery form (same generator as cozk_vec_fill_random)
-static __device__ __forceinline__ fe prf_fr(uint64_t seed, uint64_t j) {
-    uint64_t s = seed + j * 0xD1342543DE82EF95ull;
-    fe v;
-    for (;;) {
-        uint64_t w0 = sm_next(s), w1 = sm_next(s), w2 = sm_next(s), w3 = sm_next(s) & ((1ull << 62) - 1ull);
-        v.l[0] = (uint32_t)w0; v.l[1] = (uint32_t)(w0 >> 32);
-        v.l[2] = (uint32_t)w1; v.l[3] = (uint32_t)(w1 >> 32);
-        v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
-        v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
-        if (!Fr::geq_mod(v)) break;
-    }
-    return Fr::to_mont(v);
-}
-
 // out[j] = L[j] x R[j] (+ mask_j): local half of `mul_vec` (layer_output,
 // dense_interleaved_poly.rs:122-141; local product ops.rs:71-78; zero-sharing mask
-// mask_j = PRF(seed_self, ctr+j) - PRF(seed_prev, ctr+j))
+// mask_j = PRF(key_self, ctr+j) - PRF(key_prev, ctr+j), the keyed ChaCha12 PRF of prf.cuh)
 template <int NC>
 __global__ void __launch_bounds__(PT) k_layer_output(const fe* __restrict__ a, const fe* __restrict__ b, size_t len,
-                                                  fe* __restrict__ out, size_t n_out, int masked, uint64_t seed_self,
-                                                  uint64_t seed_prev, uint64_t ctr) {
+                                                  fe* __restrict__ out, size_t n_out, int masked, prf_key key_self,
+                                                  prf_key key_prev, uint64_t ctr) {
     size_t j = (size_t)blockIdx.x * PT + threadIdx.x;
     if (j >= n_out) return;
     Sh<NC> l = sh_load_or_zero<NC>(a, b, 2 * j, len), r = sh_load_or_zero<NC>(a, b, 2 * j + 1, len);
     fe v = sh_local_mul<NC>(l, r);
-    if (masked) v = Fr::add(v, Fr::sub(prf_fr(seed_self, ctr + j), prf_fr(seed_prev, ctr + j)));
+    if (masked) v = Fr::add(v, Fr::sub(prf_fr(key_self, ctr + j), prf_fr(key_prev, ctr + j)));
     fe_store(out + j, v);
 }
 
@@ -741,12 +716,12 @@ __global__ void __launch_bounds__(PT) k_layer_output(const fe* __restrict__ a, c
 template <int NC>
 __global__ void __launch_bounds__(PT) k_mul_vec_local(const fe* __restrict__ xa, const fe* __restrict__ xb,
                                                    const fe* __restrict__ ya, const fe* __restrict__ yb, size_t n,
-                                                   fe* __restrict__ out, int masked, uint64_t seed_self, uint64_t seed_prev,
+                                                   fe* __restrict__ out, int masked, prf_key key_self, prf_key key_prev,
                                                    uint64_t ctr) {
     size_t j = (size_t)blockIdx.x * PT + threadIdx.x;
     if (j >= n) return;
     fe v = sh_local_mul<NC>(sh_load<NC>(xa, xb, j), sh_load<NC>(ya, yb, j));
-    if (masked) v = Fr::add(v, Fr::sub(prf_fr(seed_self, ctr + j), prf_fr(seed_prev, ctr + j)));
+    if (masked) v = Fr::add(v, Fr::sub(prf_fr(key_self, ctr + j), prf_fr(key_prev, ctr + j)));
     fe_store(out + j, v);
 }
 
@@ -2028,106 +2003,134 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
     memcpy(pc, claim, sizeof pc);
     bool have_r = false;
     int round = 0;
-    for (; round < num_rounds; round++) {
-        if (!no_persist && ctx->resident_rounds && l->len <= ROUND_PERSIST_MAX && l->len >= 2) break;
-        int rc = cozk_layer_round(ctx, l, e, have_r ? rr : nullptr, pc, coeffs);
-        if (rc != COZK_OK) return rc;
-        if (cb(user, round, coeffs, rr, nc) != 0) {
-            ctx->last_error = "layer_prove_rounds: round callback failed";
-            return COZK_ERR_INTERNAL;
-        }
-        memcpy(out_r + 4 * round, rr, sizeof rr);
-        memcpy(pc, nc, sizeof pc);
-        have_r = true;
-    }
-    if (round == num_rounds) {  // every round ran as its own launch
-        if (num_rounds > 0) {
-            int rc = cozk_layer_bind(ctx, l, rr);
+    // the resident kernel is used when the context allows it (cozk_ctx_set_resident_rounds; by default only while this
+    // is the one live context on its device in the process) and is abandoned for the rest of the call once its watchdog
+    // has fired (a round callback that took longer than COZK_RESIDENT_TIMEOUT_S): the loop then goes on with one launch
+    // per round, from exactly the state the kernel left
+    bool allow_resident = !no_persist && ctx_resident_rounds_enabled(ctx);
+    for (;;) {
+        for (; round < num_rounds; round++) {
+            if (allow_resident && l->len <= ROUND_PERSIST_MAX && l->len >= 2) break;
+            int rc = cozk_layer_round(ctx, l, e, have_r ? rr : nullptr, pc, coeffs);
             if (rc != COZK_OK) return rc;
-            rc = cozk_spliteq_bind(ctx, e, rr);
-            if (rc != COZK_OK) return rc;
-        }
-        return cozk_layer_final_claims(ctx, l, final_claims);
-    }
-    return cozk_guard(ctx, [&] {
-        const int nrem = num_rounds - round;
-        // both ping-pong buffers of the layer must hold the current length
-        for (int w = 0; w < 2; w++) {
-            if (w != l->cur && l->cap[w] < l->len) {
-                for (int c = 0; c < 2; c++) {
-                    if (l->buf[w][c]) ctx_dev_free(l->ctx, l->buf[w][c]);
-                    l->buf[w][c] = nullptr;
-                }
-                l->buf[w][0] = dev_alloc_fe(l->len);
-                if (l->mode == COZK_MODE_REP3) l->buf[w][1] = dev_alloc_fe(l->len);
-                l->cap[w] = l->len;
+            if (cb(user, round, coeffs, rr, nc) != 0) {
+                ctx->last_error = "layer_prove_rounds: round callback failed";
+                return COZK_ERR_INTERNAL;
             }
-        }
-        if (!ctx->mailbox) HIP_TRY(hipHostMalloc(&ctx->mailbox, sizeof(RoundMailbox), hipHostMallocMapped | hipHostMallocCoherent));
-        RoundMailbox* mb = (RoundMailbox*)ctx->mailbox;
-        memset(mb, 0, sizeof *mb);
-        std::atomic_thread_fence(std::memory_order_seq_cst);
-        fe r_first = have_r ? fe_from_u64x4(rr) : Fr::zero();
-        const long long ticks = (long long)resident_timeout_s() * MB_TICKS_PER_S;
-        if (l->mode == COZK_MODE_REP3)
-            k_layer_rounds_persistent<2><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], l->buf[0][1], l->buf[1][0], l->buf[1][1], l->cur, l->len, e->E1[0], e->E1[1],
-                                                                   e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
-        else
-            k_layer_rounds_persistent<1><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], nullptr, l->buf[1][0], nullptr, l->cur, l->len, e->E1[0], e->E1[1], e->c1,
-                                                                   e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
-        HIP_TRY(hipGetLastError());
-        volatile uint32_t* res_seq = &mb->res_seq;
-        volatile uint32_t* status = &mb->status;
-        auto give_up = [&](const char* why) {
-            *(volatile uint32_t*)&mb->abort = 1;
-            std::atomic_thread_fence(std::memory_order_seq_cst);
-            (void)hipStreamSynchronize(ctx->stream);
-            throw CozkError(COZK_ERR_INTERNAL, why);
-        };
-        auto wait_result = [&](uint32_t want) {
-            auto t0 = std::chrono::steady_clock::now();
-            uint64_t spins = 0;
-            while (*res_seq != want) {
-                if (*status) give_up("layer_prove_rounds: the resident kernel gave up waiting for the host");
-                __builtin_ia32_pause();
-                if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(resident_timeout_s() + 5))
-                    give_up("layer_prove_rounds: no result from the resident kernel");
-            }
-            std::atomic_thread_fence(std::memory_order_acquire);
-        };
-        for (int j = 0; j < nrem; j++) {
-            wait_result((uint32_t)j + 1);
-            fe s0 = mb->res[0], s2 = mb->res[1], s3 = mb->res[2];
-            fe ev[4] = {s0, Fr::sub(fe_from_u64x4(pc), s0), s2, s3};
-            fe cf[4];
-            unipoly_from_evals(ev, 4, cf);
-            for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], coeffs + 4 * i);
-            if (cb(user, round + j, coeffs, rr, nc) != 0) give_up("layer_prove_rounds: round callback failed");
-            memcpy(out_r + 4 * (round + j), rr, sizeof rr);
+            memcpy(out_r + 4 * round, rr, sizeof rr);
             memcpy(pc, nc, sizeof pc);
-            mb->r = fe_from_u64x4(rr);
-            std::atomic_thread_fence(std::memory_order_release);
-            *(volatile uint32_t*)&mb->cmd_seq = (uint32_t)j + 1;
+            have_r = true;
         }
-        wait_result((uint32_t)nrem + 1);
-        for (int k = 0; k < 4; k++) fe_to_u64x4(mb->res[k], final_claims + 4 * k);
-        if (getenv("COZK_TRACE_ROUNDS"))
-            fprintf(stderr, "[mailbox] %d rounds: device us/round: wait %.1f bind %.1f cubic %.1f publish %.1f\n", nrem,
-                    mb->dbg[0] / 100.0 / (nrem + 1), mb->dbg[1] / 100.0 / (nrem + 1), mb->dbg[2] / 100.0 / nrem, mb->dbg[3] / 100.0 / nrem);
-        // mirror the kernel's bookkeeping: one bind per remaining round (+ the pending one it started with)
-        int binds = nrem + (have_r ? 1 : 0);
-        for (int b = 0; b < binds; b++) {
-            l->len = 2 * ((l->len + 3) / 4);
-            l->cur = 1 - l->cur;
-            if (e->E1_len == 1) {
-                e->E2_len /= 2;
-                e->c2 = 1 - e->c2;
-            } else {
-                e->E1_len /= 2;
-                e->c1 = 1 - e->c1;
+        if (round == num_rounds) {  // every remaining round ran as its own launch
+            if (have_r) {
+                int rc = cozk_layer_bind(ctx, l, rr);
+                if (rc != COZK_OK) return rc;
+                rc = cozk_spliteq_bind(ctx, e, rr);
+                if (rc != COZK_OK) return rc;
             }
+            return cozk_layer_final_claims(ctx, l, final_claims);
         }
-    });
+        int rounds_done = -1;  // >= 0: the resident kernel timed out after that many of its rounds; fall back
+        int rc = cozk_guard(ctx, [&] {
+            const int nrem = num_rounds - round;
+            // both ping-pong buffers of the layer must hold the current length
+            for (int w = 0; w < 2; w++) {
+                if (w != l->cur && l->cap[w] < l->len) {
+                    for (int c = 0; c < 2; c++) {
+                        if (l->buf[w][c]) ctx_dev_free(l->ctx, l->buf[w][c]);
+                        l->buf[w][c] = nullptr;
+                    }
+                    l->buf[w][0] = dev_alloc_fe(l->len);
+                    if (l->mode == COZK_MODE_REP3) l->buf[w][1] = dev_alloc_fe(l->len);
+                    l->cap[w] = l->len;
+                }
+            }
+            if (!ctx->mailbox) HIP_TRY(hipHostMalloc(&ctx->mailbox, sizeof(RoundMailbox), hipHostMallocMapped | hipHostMallocCoherent));
+            RoundMailbox* mb = (RoundMailbox*)ctx->mailbox;
+            memset(mb, 0, sizeof *mb);
+            std::atomic_thread_fence(std::memory_order_seq_cst);
+            fe r_first = have_r ? fe_from_u64x4(rr) : Fr::zero();
+            const long long ticks = (long long)resident_timeout_s() * MB_TICKS_PER_S;
+            if (l->mode == COZK_MODE_REP3)
+                k_layer_rounds_persistent<2><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], l->buf[0][1], l->buf[1][0], l->buf[1][1], l->cur, l->len, e->E1[0], e->E1[1],
+                                                                       e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
+            else
+                k_layer_rounds_persistent<1><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], nullptr, l->buf[1][0], nullptr, l->cur, l->len, e->E1[0], e->E1[1], e->c1,
+                                                                       e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
+            HIP_TRY(hipGetLastError());
+            volatile uint32_t* res_seq = &mb->res_seq;
+            volatile uint32_t* status = &mb->status;
+            auto give_up = [&](const char* why) {
+                *(volatile uint32_t*)&mb->abort = 1;
+                std::atomic_thread_fence(std::memory_order_seq_cst);
+                (void)hipStreamSynchronize(ctx->stream);
+                throw CozkError(COZK_ERR_INTERNAL, why);
+            };
+            // false: the kernel's watchdog fired (it waited resident_timeout_s() for the host's challenge and left)
+            auto wait_result = [&](uint32_t want) -> bool {
+                auto t0 = std::chrono::steady_clock::now();
+                uint64_t spins = 0;
+                while (*res_seq != want) {
+                    if (*status == 1) return false;
+                    if (*status) give_up("layer_prove_rounds: the resident kernel stopped");
+                    __builtin_ia32_pause();
+                    if ((++spins & 0xfffff) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(resident_timeout_s() + 5))
+                        give_up("layer_prove_rounds: no result from the resident kernel");
+                }
+                std::atomic_thread_fence(std::memory_order_acquire);
+                return true;
+            };
+            // mirror the kernel's bookkeeping: one bind per completed round (+ the pending one it started with)
+            auto mirror_binds = [&](int binds) {
+                for (int b = 0; b < binds; b++) {
+                    l->len = 2 * ((l->len + 3) / 4);
+                    l->cur = 1 - l->cur;
+                    if (e->E1_len == 1) {
+                        e->E2_len /= 2;
+                        e->c2 = 1 - e->c2;
+                    } else {
+                        e->E1_len /= 2;
+                        e->c1 = 1 - e->c1;
+                    }
+                }
+            };
+            const int bind_first = have_r ? 1 : 0;
+            int j = 0;
+            bool alive = true;
+            for (; j < nrem; j++) {
+                if (!(alive = wait_result((uint32_t)j + 1))) break;
+                fe s0 = mb->res[0], s2 = mb->res[1], s3 = mb->res[2];
+                fe ev[4] = {s0, Fr::sub(fe_from_u64x4(pc), s0), s2, s3};
+                fe cf[4];
+                unipoly_from_evals(ev, 4, cf);
+                for (int i = 0; i < 4; i++) fe_to_u64x4(cf[i], coeffs + 4 * i);
+                if (cb(user, round + j, coeffs, rr, nc) != 0) give_up("layer_prove_rounds: round callback failed");
+                memcpy(out_r + 4 * (round + j), rr, sizeof rr);
+                memcpy(pc, nc, sizeof pc);
+                have_r = true;
+                mb->r = fe_from_u64x4(rr);
+                std::atomic_thread_fence(std::memory_order_release);
+                *(volatile uint32_t*)&mb->cmd_seq = (uint32_t)j + 1;
+            }
+            if (alive) alive = wait_result((uint32_t)nrem + 1);
+            if (!alive) {
+                // the kernel left while the host was inside the callback of round j - 1 (or before the first result):
+                // it published j results and bound j - 1 (+ bind_first) times; the challenge of round j - 1 is pending
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                mirror_binds(j > 0 ? j - 1 + bind_first : 0);
+                rounds_done = j;
+                return;
+            }
+            for (int k = 0; k < 4; k++) fe_to_u64x4(mb->res[k], final_claims + 4 * k);
+            if (getenv("COZK_TRACE_ROUNDS"))
+                fprintf(stderr, "[mailbox] %d rounds: device us/round: wait %.1f bind %.1f cubic %.1f publish %.1f\n", nrem,
+                        mb->dbg[0] / 100.0 / (nrem + 1), mb->dbg[1] / 100.0 / (nrem + 1), mb->dbg[2] / 100.0 / nrem, mb->dbg[3] / 100.0 / nrem);
+            mirror_binds(nrem + bind_first);
+        });
+        if (rc != COZK_OK || rounds_done < 0) return rc;
+        round += rounds_done;
+        allow_resident = false;
+    }
 }
 
 // cozk_layer_prove_rounds for a worker sub-net, which cannot derive g(1) from the (global) previous claim and sends
@@ -2192,10 +2195,15 @@ int cozk_layer_final_claims(cozk_ctx* ctx, const cozk_layer* l, uint64_t out[16]
 // local half of layer_output / mul_vec: out[j] = L[j] x R[j] + mask_j (additive share c.a);
 // masked = 0 for the plain prover (then out IS the next layer).  The ring reshare that turns c.a
 // into (c.a, c.b = prev's c.a) is the network seam (cozk_layer_create on the two buffers).
-int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, uint64_t seed_self, uint64_t seed_prev,
+int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, const uint8_t* key_self_b, const uint8_t* key_prev_b,
                             uint64_t counter, cozk_vec** out) {
     return cozk_guard(ctx, [&] {
-        COZK_REQUIRE(ctx && l && out && l->len >= 2, "layer_output_local: bad argument");
+        COZK_REQUIRE(ctx && l && out && l->len >= 2 && (!masked || (key_self_b && key_prev_b)), "layer_output_local: bad argument");
+        prf_key seed_self{}, seed_prev{};
+        if (masked) {
+            seed_self = prf_key_from_bytes(key_self_b);
+            seed_prev = prf_key_from_bytes(key_prev_b);
+        }
         size_t n = (l->len + 1) / 2;
         fe* d = dev_alloc_fe(n);
         const fe* a = l->buf[l->cur][0];
@@ -2209,11 +2217,17 @@ int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, uint
 
 // rep3::arithmetic::mul_vec local half on two share vectors (x, y given as SoA component vectors)
 int cozk_rep3_mul_vec_local(cozk_ctx* ctx, int mode, const cozk_vec* xa, const cozk_vec* xb, const cozk_vec* ya,
-                            const cozk_vec* yb, int masked, uint64_t seed_self, uint64_t seed_prev, uint64_t counter,
+                            const cozk_vec* yb, int masked, const uint8_t* key_self_b, const uint8_t* key_prev_b, uint64_t counter,
                             cozk_vec** out) {
     return cozk_guard(ctx, [&] {
-        COZK_REQUIRE(ctx && xa && ya && out && xa->n == ya->n && (mode == COZK_MODE_PLAIN || (xb && yb && xb->n == xa->n && yb->n == xa->n)),
+        COZK_REQUIRE(ctx && xa && ya && out && xa->n == ya->n && (mode == COZK_MODE_PLAIN || (xb && yb && xb->n == xa->n && yb->n == xa->n)) &&
+                         (!masked || (key_self_b && key_prev_b)),
                      "mul_vec_local: bad argument");
+        prf_key seed_self{}, seed_prev{};
+        if (masked) {
+            seed_self = prf_key_from_bytes(key_self_b);
+            seed_prev = prf_key_from_bytes(key_prev_b);
+        }
         size_t n = xa->n;
         fe* d = dev_alloc_fe(n);
         if (mode == COZK_MODE_REP3)
@@ -2234,8 +2248,8 @@ int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out
         fe* d = ctx->scratch.as<fe>();
         const fe* a = l->buf[l->cur][0];
         const fe* b = l->buf[l->cur][1];
-        if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, 0, 0, 0);
-        else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, 0, 0, 0);
+        if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, prf_key{}, prf_key{}, 0);
+        else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, 0, prf_key{}, prf_key{}, 0);
         HIP_TRY(hipGetLastError());
         std::vector<fe> h(n);
         fetch_fe(ctx, d, n, h.data());

@@ -61,6 +61,27 @@ def point_from_abi(xy, inf):
     return (x, y)
 
 
+def wire_g1_encode(pt):
+    """ark-serialize uncompressed G1Affine bytes of an affine point (cozk_wire_g1_encode; host only)"""
+    xy, inf = point_to_abi(pt)
+    out = (ctypes.c_uint8 * 64)()
+    rc = L.lib().cozk_wire_g1_encode(xy.ctypes.data, inf, out)
+    if rc != L.OK:
+        raise L.CozkError(rc, "wire_g1_encode")
+    return bytes(out)
+
+
+def wire_g1_decode(b):
+    """inverse, with arkworks' Validate::Yes checks (raises CozkError for bytes arkworks would reject)"""
+    buf = (ctypes.c_uint8 * 64)(*bytes(b))
+    xy = np.zeros(8, dtype=np.uint64)
+    inf = ctypes.c_int()
+    rc = L.lib().cozk_wire_g1_decode(buf, xy.ctypes.data, ctypes.byref(inf))
+    if rc != L.OK:
+        raise L.CozkError(rc, "wire_g1_decode: invalid point encoding")
+    return point_from_abi(xy, inf.value)
+
+
 class Context:
     """One per (party, GPU).  Not thread-safe (single-owner, like an IoContext fork)."""
 
@@ -82,6 +103,11 @@ class Context:
 
     def synchronize(self):
         self.check(self._l.cozk_ctx_synchronize(self.h))
+
+    def set_resident_rounds(self, enable):
+        """True / False: force the resident round kernel of cozk_layer_prove_rounds on / off; None: the automatic
+        default (on only while this is the one live context on its device in the process)"""
+        self.check(self._l.cozk_ctx_set_resident_rounds(self.h, -1 if enable is None else (1 if enable else 0)))
 
     def close(self):
         if self.h:
@@ -190,11 +216,19 @@ class Vec:
             return mont_limbs_to_int(a)
         return [int(x) for x in a]
 
-    def rep3_share(self, seed0, seed1, party):
-        """Rep3 shares (a, b) of this secret vector for `party` (cozk_rep3_share_vec)"""
+    def rep3_share(self, key0, key1, party, counter=0):
+        """Rep3 shares (a, b) of this secret vector for `party` (cozk_rep3_share_vec); key0 / key1 = 32-byte PRF keys"""
         a, b = ctypes.c_void_p(), ctypes.c_void_p()
-        self.ctx.check(self.ctx._l.cozk_rep3_share_vec(self.ctx.h, self.h, seed0, seed1, party, ctypes.byref(a), ctypes.byref(b)))
+        self.ctx.check(self.ctx._l.cozk_rep3_share_vec(self.ctx.h, self.h, L.prf_key(key0), L.prf_key(key1), counter, party,
+                                                       ctypes.byref(a), ctypes.byref(b)))
         return Vec(self.ctx, a, L.SCALAR_FR), Vec(self.ctx, b, L.SCALAR_FR)
+
+    @classmethod
+    def prf(cls, ctx, n, key, counter=0):
+        """out[i] = PRF(key, counter + i): the keyed ChaCha12 stream every share / mask is drawn from"""
+        v = cls.alloc(ctx, n, L.SCALAR_FR)
+        ctx.check(ctx._l.cozk_vec_fill_prf(ctx.h, v.h, L.prf_key(key), counter))
+        return v
 
     def binop(self, op, other, base_field=False):
         out = Vec.alloc(self.ctx, len(self), L.SCALAR_FR)

@@ -331,9 +331,9 @@ class Rep3DenseInterleavedPolynomial:
             return (v[0], v[1]), (v[2], v[3])
         return v[0], v[2]
 
-    def layer_output_local(self, masked=False, seed_self=0, seed_prev=0, counter=0):
+    def layer_output_local(self, masked=False, key_self=None, key_prev=None, counter=0):
         h = ctypes.c_void_p()
-        self.ctx.check(self.ctx._l.cozk_layer_output_local(self.ctx.h, self.h, 1 if masked else 0, seed_self, seed_prev,
+        self.ctx.check(self.ctx._l.cozk_layer_output_local(self.ctx.h, self.h, 1 if masked else 0, L.prf_key(key_self), L.prf_key(key_prev),
                                                            counter, ctypes.byref(h)))
         return Vec(self.ctx, h, L.SCALAR_FR)
 
@@ -353,6 +353,18 @@ class Rep3DenseInterleavedPolynomial:
             self.free()
         except Exception:
             pass
+
+
+def rep3_mul_vec_local(ctx, xa, xb, ya, yb, key_self=None, key_prev=None, counter=0):
+    """rep3::arithmetic::mul_vec, local half (cozk_rep3_mul_vec_local): out[j] = x[j] x y[j] as an additive share,
+    plus the zero-sharing mask PRF(key_self, counter + j) - PRF(key_prev, counter + j) when keys are given.
+    xb = yb = None: plain vectors."""
+    mode = L.MODE_PLAIN if xb is None else L.MODE_REP3
+    masked = key_self is not None
+    h = ctypes.c_void_p()
+    ctx.check(ctx._l.cozk_rep3_mul_vec_local(ctx.h, mode, xa.h, xb.h if xb is not None else None, ya.h, yb.h if yb is not None else None,
+                                             1 if masked else 0, L.prf_key(key_self), L.prf_key(key_prev), counter, ctypes.byref(h)))
+    return Vec(ctx, h, L.SCALAR_FR)
 
 
 def prod_sumcheck_evals(polys, degree):

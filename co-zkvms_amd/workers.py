@@ -22,7 +22,7 @@ class RingNet(ctypes.Structure):
 
 
 class WorkerParams(ctypes.Structure):
-    _fields_ = [("mode", ctypes.c_int), ("party", ctypes.c_int), ("seed_self", ctypes.c_uint64), ("seed_prev", ctypes.c_uint64),
+    _fields_ = [("mode", ctypes.c_int), ("party", ctypes.c_int), ("key_self", ctypes.c_uint8 * 32), ("key_prev", ctypes.c_uint8 * 32),
                 ("mask_counter", ctypes.c_uint64)]
 
 
@@ -60,8 +60,10 @@ class CallbackStar:
         self.net = StarNet(None, self._s, self._r)
 
 
-def _params(mode, party=0, seed_self=0, seed_prev=0, counter=0):
-    return WorkerParams(L.MODE_PLAIN if mode == "plain" else L.MODE_REP3, party, seed_self, seed_prev, counter)
+def _params(mode, party=0, key_self=None, key_prev=None, counter=0):
+    ks = (ctypes.c_uint8 * 32)(*(L.prf_key(key_self) or bytes(32)))
+    kp = (ctypes.c_uint8 * 32)(*(L.prf_key(key_prev) or bytes(32)))
+    return WorkerParams(L.MODE_PLAIN if mode == "plain" else L.MODE_REP3, party, ks, kp, counter)
 
 
 def _check(ctx, rc, star):

@@ -62,9 +62,14 @@ const char* cozk_last_error(cozk_ctx* ctx);
 /* cozk_layer_prove_rounds keeps one single-workgroup kernel resident for the tail of a layer's sumcheck; while it
  * waits for the host's challenge, kernels of other streams that the driver mapped to the same hardware queue
  * cannot start.  That is harmless for independent provers, but provers that need EACH OTHER's round messages to
- * make progress (several parties of one protocol run driven from one process on one GPU) could then wait for
- * each other forever (the kernel's watchdog -- 10 s, COZK_RESIDENT_TIMEOUT_S -- turns that into an error).  Disable it for such contexts;
- * one party per process -- the reference's deployment -- is safe.  Default: enabled. */
+ * make progress (several parties of one protocol run driven from one process on one GPU) would then wait for each
+ * other.  libcozk cannot see such dependencies, so the DEFAULT is automatic and safe: the resident kernel is used
+ * only while the context is the one live context on its device in this process (one party per process -- the
+ * reference's deployment); as soon as a second context exists, rounds are one launch each.  enable > 0 forces it on
+ * (the host vouches that its contexts are independent), 0 off, < 0 restores the automatic default.  If the kernel's
+ * watchdog fires anyway (a round callback slower than COZK_RESIDENT_TIMEOUT_S, default 10 s -- e.g. a peer that a
+ * transport with a longer timeout is still waiting for), the remaining rounds of that call fall back to
+ * per-round launches; the proof is unaffected. */
 int cozk_ctx_set_resident_rounds(cozk_ctx* ctx, int enable);
 int cozk_ctx_synchronize(cozk_ctx* ctx);
 /* raw hipStream_t of the context (so a host can order its own work / events against it) */
@@ -80,17 +85,25 @@ int cozk_vec_free(cozk_vec* v);
 size_t cozk_vec_len(const cozk_vec* v);
 /* raw device pointer (for zero-copy interop with the host's own device buffers, e.g. RCCL staging) */
 void* cozk_vec_device_ptr(const cozk_vec* v);
-/* synthetic data: element i draws from SplitMix64(seed + i * 0xD1342543DE82EF95): FR = canonical value
- * rejection-sampled below r, stored in Montgomery form; small kinds = low bits.  max_bits > 0 masks
- * the value to that many bits (e.g. 1 for 0/1 flags). */
+/* SYNTHETIC TEST DATA ONLY (benchmarks, fixtures): element i draws from SplitMix64(seed + i * 0xD1342543DE82EF95):
+ * FR = canonical value rejection-sampled below r, stored in Montgomery form; small kinds = low bits.  max_bits > 0
+ * masks the value to that many bits (e.g. 1 for 0/1 flags).  SplitMix64 is not a PRF: nothing secret is ever drawn
+ * from it -- shares and masks come from the keyed ChaCha12 PRF below. */
 int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits);
 
+/* Keyed PRF of the engine: PRF(key, j) = element j of the ChaCha12 stream keyed with the 32-byte `key` (one block per
+ * element: counter = j, rejection-sampled below r; csrc/prf.cuh).  Keys are what the reference's parties exchange as
+ * 32-byte ChaCha seeds (mpc-types/src/protocols/rep3.rs:29,177; mpc-core/src/protocols/rep3/network.rs:190-211) and
+ * come from the host's CryptoRng; (key, counter range) pairs must never be reused for different data. */
+#define COZK_PRF_KEY_BYTES 32
+/* out[i] = PRF(key, counter + i), Montgomery form (FR vector) */
+int cozk_vec_fill_prf(cozk_ctx* ctx, cozk_vec* v, const uint8_t key[COZK_PRF_KEY_BYTES], uint64_t counter);
 /* Rep3 sharing of a secret vector on the device -- the witness scatter (rep3::share_field_element,
- * mpc-core/src/protocols/rep3/arithmetic.rs:21-33; jolt/vm/../witness.rs generate_poly_shares_rep3): t0 = stream(seed0),
- * t1 = stream(seed1) (the generator of cozk_vec_fill_random), t2 = v - t0 - t1; returns `party`'s (a, b) =
- * (t0, t2) / (t1, t0) / (t2, t1).  The dealer calls it once per party (or every party derives its own pair from
- * shared seeds when v is public to the dealer only). */
-int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, uint64_t seed0, uint64_t seed1, int party,
+ * mpc-core/src/protocols/rep3/arithmetic.rs:21-33; jolt/vm/../witness.rs generate_poly_shares_rep3):
+ * t0[i] = PRF(key0, counter + i), t1[i] = PRF(key1, counter + i), t2 = v - t0 - t1; returns `party`'s (a, b) =
+ * (t0, t2) / (t1, t0) / (t2, t1).  The dealer calls it once per party. */
+int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES],
+                        const uint8_t key1[COZK_PRF_KEY_BYTES], uint64_t counter, int party,
                         cozk_vec** out_a, cozk_vec** out_b);
 /* element-wise out[i] = a[i] (op) b[i] on 32-byte field elements: the local arithmetic of
  * mpc-types/src/protocols/additive/ops.rs (AdditivePrimeFieldShare is repr(transparent) over F).
@@ -266,13 +279,14 @@ int cozk_layer_compute_cubic_evals(cozk_ctx* ctx, const cozk_layer* l, const coz
 int cozk_layer_final_claims(cozk_ctx* ctx, const cozk_layer* l, uint64_t out[16]);
 /* local half of layer_output -> mul_vec (dense_interleaved_poly.rs:122-141; local product
  * mpc-types/src/protocols/rep3/arithmetic/ops.rs:71-78): out[j] = L[j] x R[j] + mask_j, where
- * mask_j = PRF(seed_self, counter + j) - PRF(seed_prev, counter + j) when masked != 0 */
-int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, uint64_t seed_self,
-                            uint64_t seed_prev, uint64_t counter, cozk_vec** out);
+ * mask_j = PRF(key_self, counter + j) - PRF(key_prev, counter + j) when masked != 0 (key_self is shared with the
+ * next party, key_prev with the previous one: the three masks sum to zero; keys may be NULL when masked == 0) */
+int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, const uint8_t* key_self,
+                            const uint8_t* key_prev, uint64_t counter, cozk_vec** out);
 /* rep3::arithmetic::mul_vec, local half, on SoA share vectors */
 int cozk_rep3_mul_vec_local(cozk_ctx* ctx, int mode, const cozk_vec* xa, const cozk_vec* xb,
-                            const cozk_vec* ya, const cozk_vec* yb, int masked, uint64_t seed_self,
-                            uint64_t seed_prev, uint64_t counter, cozk_vec** out);
+                            const cozk_vec* ya, const cozk_vec* yb, int masked, const uint8_t* key_self,
+                            const uint8_t* key_prev, uint64_t counter, cozk_vec** out);
 /* claimed_outputs (grand_product.rs:266-272): out = (len/2) x 4 u64 additive products */
 int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out);
 
@@ -301,15 +315,24 @@ typedef struct cozk_ring_net {
     int (*reshare)(void* user, const void* dev_send, void* dev_recv, size_t nbytes);
 } cozk_ring_net;
 
+/* ---------------------------------------------------------------- wire format -------------- */
+/* ark-serialize *uncompressed* G1Affine, the encoding of every point the workers send and of the proof structs
+ * PST13Commitment{nv, g_product} / Proof{proofs} (mpc-net/src/rep3/quic/worker.rs:187-219; co-jolt/src/poly/commitment/
+ * pst13.rs:397-401): x || y as 32-byte LE canonical integers, SWFlags in the top bits of the last byte (bit 6 = infinity,
+ * bit 7 = y > -y).  Host-only (no device needed).  decode validates like arkworks' Validate::Yes -- canonical
+ * coordinates, consistent flags, on the curve -- and returns COZK_ERR_INVALID_ARG for bytes arkworks would reject. */
+int cozk_wire_g1_encode(const uint64_t xy[8], int infinity, uint8_t out[64]);
+int cozk_wire_g1_decode(const uint8_t in[64], uint64_t xy[8], int* infinity);
+
 /* ---------------------------------------------------------------- worker drivers ----------- */
 /* The C++ round loops (csrc/host/prover.hpp) run against host-supplied nets: the calls a Rust host makes
  * when it wants the whole loop rather than the per-round kernels. */
 typedef struct cozk_worker_params {
     int mode;               /* COZK_MODE_PLAIN / COZK_MODE_REP3 */
     int party;              /* PartyID 0..2 */
-    uint64_t seed_self;     /* zero-sharing PRF key shared with the next party */
-    uint64_t seed_prev;     /* ... with the previous party */
-    uint64_t mask_counter;  /* starting counter of the zero-sharing stream */
+    uint8_t key_self[COZK_PRF_KEY_BYTES]; /* zero-sharing PRF key shared with the next party */
+    uint8_t key_prev[COZK_PRF_KEY_BYTES]; /* ... with the previous party */
+    uint64_t mask_counter;                /* starting counter of the zero-sharing stream */
 } cozk_worker_params;
 /* construct + prove_grand_product_worker (co-jolt/src/subprotocols/grand_product.rs:111-130,239-255) on a
  * clone of `leaves`; ring may be NULL for the plain prover.  out_r = final point (r_cap x 4 u64). */

@@ -78,3 +78,11 @@ def msm(xy, inf, scalars_mont):
     lib().orc_msm(xy.ctypes.data_as(ctypes.c_void_p), inf.ctypes.data_as(ctypes.c_void_p), sc.ctypes.data_as(ctypes.c_void_p),
                   ctypes.c_size_t(xy.shape[0]), out.ctypes.data_as(ctypes.c_void_p), ctypes.byref(oi))
     return out, oi.value
+
+
+def prf_fr(key, counter, n):
+    """PRF(key, counter + i) for i < n as Montgomery limbs (n, 4) -- the C restatement of csrc/prf.cuh"""
+    import numpy as np
+    out = np.zeros((n, 4), dtype=np.uint64)
+    lib().orc_prf_fr(ctypes.c_char_p(bytes(key)), ctypes.c_uint64(counter), ctypes.c_size_t(n), out.ctypes.data_as(ctypes.c_void_p))
+    return out

@@ -29,9 +29,7 @@ def _ser_vec(v):
 
 
 def _ser_g1(pt):
-    if pt is None:
-        return b"\x00" * 63 + b"\x40"
-    return pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+    return O.ser_g1(pt)
 
 
 def _shares_of(seed, n, mode):
@@ -39,10 +37,7 @@ def _shares_of(seed, n, mode):
     v = O.synthetic_fr(seed, n)
     if mode == "plain":
         return [v]
-    t0 = O.synthetic_fr(seed + 1, n)
-    t1 = O.synthetic_fr(seed + 2, n)
-    t2 = [(a - b - c) % R for a, b, c in zip(v, t0, t1)]
-    return [list(zip(t0, t2)), list(zip(t1, t0)), list(zip(t2, t1))]
+    return O.rep3_share_vec(v, O.harness_prf_key(seed, 101), O.harness_prf_key(seed, 102))
 
 
 def _pst_setup(seed, nv):
@@ -145,7 +140,7 @@ def run(cfg):
         else:
             lr = [O.interleaved_uninterleave(prev[p]) for p in range(3)]
             n_out = len(lr[0][0])
-            prf = [O.synthetic_fr(seed + 900000 + p, mask_ctr + n_out)[mask_ctr:] for p in range(3)]
+            prf = [O.prf_fr_vec(O.harness_prf_key(seed, p), mask_ctr, n_out) for p in range(3)]
             masks = [[(prf[p][jj] - prf[(p + 2) % 3][jj]) % R for jj in range(n_out)] for p in range(3)]
             layers.append(O.rep3_mul_vec([x[0] for x in lr], [x[1] for x in lr], masks))
             mask_ctr += n_out

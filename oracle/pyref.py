@@ -934,6 +934,131 @@ def synthetic_small(seed, n, bits):
 
 
 # --------------------------------------------------------------------------------------------
+# ark-serialize uncompressed encodings (the wire format of mpc-net, mpc-net/src/rep3/quic/worker.rs:187-219, and of the
+# proof structs PST13Commitment{nv, g_product} / Proof{proofs}, co-jolt/src/poly/commitment/pst13.rs:397-401).
+# From upstream knowledge of ark-serialize / ark-ec 0.5 (out of tree; the reference holds no serialized bytes to pin
+# them): Fr = 32-byte LE canonical integer; usize / Vec length = u64 LE; G1Affine uncompressed = x || y with SWFlags in
+# the two spare top bits of the last byte: bit 6 = infinity (x = y = 0), bit 7 = y > -y (`to_flags()` is passed to
+# y.serialize_with_flags in both modes); readers ignore bit 7 when uncompressed.
+# --------------------------------------------------------------------------------------------
+def ser_u64(v):
+    return int(v).to_bytes(8, "little")
+
+
+def ser_fr(x):
+    return (x % R).to_bytes(32, "little")
+
+
+def ser_vec_fr(v):
+    return ser_u64(len(v)) + b"".join(ser_fr(x) for x in v)
+
+
+def ser_g1(pt):
+    if pt is None:
+        return b"\x00" * 63 + b"\x40"
+    x, y = pt
+    out = bytearray(x.to_bytes(32, "little") + y.to_bytes(32, "little"))
+    if y > (P - y) % P:
+        out[63] |= 0x80
+    return bytes(out)
+
+
+def deser_g1(b):
+    """inverse of ser_g1 with arkworks' Validate::Yes checks: canonical coordinates, flags, on-curve"""
+    assert len(b) == 64
+    flags = b[63] & 0xC0
+    x = int.from_bytes(b[:32], "little")
+    y = int.from_bytes(b[32:], "little") & ((1 << 254) - 1)
+    if flags == 0xC0 or x >= P or y >= P:
+        raise ValueError("invalid point encoding")
+    if flags & 0x40:
+        if x or y:
+            raise ValueError("infinity with non-zero coordinates")
+        return None
+    if not g1_is_on_curve((x, y)):
+        raise ValueError("not on the curve")
+    return (x, y)
+
+
+# --------------------------------------------------------------------------------------------
+# keyed PRF of the engine (co-zkvms_amd/csrc/prf.cuh): element j of a stream is one ChaCha12 block.
+# The reference draws shares and masks from ChaCha12 streams keyed with 32-byte seeds the parties exchange
+# (mpc-types/src/protocols/rep3.rs:29,177; mpc-core/src/protocols/rep3/network.rs:190-211); random access
+# per element replaces the sequential stream.  ChaCha itself is pinned by the RFC 8439 2.3.2 block vector
+# (20 rounds; tests/test_oracle.py) -- the 12-round variant differs only in the loop count.
+# --------------------------------------------------------------------------------------------
+_M32 = 0xFFFFFFFF
+
+
+def _rotl32(v, n):
+    return ((v << n) | (v >> (32 - n))) & _M32
+
+
+def _chacha_qr(x, a, b, c, d):
+    x[a] = (x[a] + x[b]) & _M32; x[d] = _rotl32(x[d] ^ x[a], 16)
+    x[c] = (x[c] + x[d]) & _M32; x[b] = _rotl32(x[b] ^ x[c], 12)
+    x[a] = (x[a] + x[b]) & _M32; x[d] = _rotl32(x[d] ^ x[a], 8)
+    x[c] = (x[c] + x[d]) & _M32; x[b] = _rotl32(x[b] ^ x[c], 7)
+
+
+def chacha_block_words(state, rounds):
+    """the ChaCha block function on a 16-word state: `rounds` / 2 double rounds + feed-forward"""
+    x = list(state)
+    for _ in range(rounds // 2):
+        _chacha_qr(x, 0, 4, 8, 12); _chacha_qr(x, 1, 5, 9, 13); _chacha_qr(x, 2, 6, 10, 14); _chacha_qr(x, 3, 7, 11, 15)
+        _chacha_qr(x, 0, 5, 10, 15); _chacha_qr(x, 1, 6, 11, 12); _chacha_qr(x, 2, 7, 8, 13); _chacha_qr(x, 3, 4, 9, 14)
+    return [(a + b) & _M32 for a, b in zip(x, state)]
+
+
+_CHACHA_CONST = [0x61707865, 0x3320646E, 0x79622D32, 0x6B206574]
+_PRF_DOMAIN = 0x4B5A4F43  # "COZK"
+
+
+def prf_block(key, counter, attempt):
+    """prf.cuh chacha12_block: state = constants | key | counter (64 bit) | domain | attempt"""
+    assert len(key) == 32
+    k = [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)]
+    st = _CHACHA_CONST + k + [counter & _M32, (counter >> 32) & _M32, _PRF_DOMAIN, attempt]
+    return chacha_block_words(st, 12)
+
+
+def prf_fr(key, j):
+    """PRF(key, j): the first of (words 0..7, words 8..15) of block (j, attempt), top word masked to 30 bits,
+    that is below r; next attempt if neither is.  Canonical integer (the engine returns its Montgomery form)."""
+    attempt = 0
+    while True:
+        w = prf_block(key, j, attempt)
+        for half in range(2):
+            ws = w[8 * half:8 * half + 8]
+            ws[7] &= 0x3FFFFFFF
+            v = sum(x << (32 * i) for i, x in enumerate(ws))
+            if v < R:
+                return v
+        attempt += 1
+
+
+def prf_fr_vec(key, counter, n):
+    return [prf_fr(key, counter + i) for i in range(n)]
+
+
+def harness_prf_key(seed, idx):
+    """keys of the synthetic harness runs (csrc/host/prover.hpp harness_prf_key): a real host supplies the 32-byte
+    seeds its parties exchanged; the harness expands (run seed, key index) so all parties agree without an exchange"""
+    s = (seed ^ (0xC0DEC0DE + idx * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+    g = SplitMix64(s)
+    return b"".join(g.next().to_bytes(8, "little") for _ in range(4))
+
+
+def rep3_share_vec(v, key0, key1, counter=0):
+    """cozk_rep3_share_vec for all three parties (rep3::share_field_element, mpc-core/src/protocols/rep3/
+    arithmetic.rs:21-33): t0 = PRF(key0, .), t1 = PRF(key1, .), t2 = v - t0 - t1; P0 (t0, t2), P1 (t1, t0), P2 (t2, t1)"""
+    t0 = prf_fr_vec(key0, counter, len(v))
+    t1 = prf_fr_vec(key1, counter, len(v))
+    t2 = [(a - b - c) % R for a, b, c in zip(v, t0, t1)]
+    return [list(zip(t0, t2)), list(zip(t1, t0)), list(zip(t2, t1))]
+
+
+# --------------------------------------------------------------------------------------------
 # generic product sumcheck (prove_arbitrary_worker) and co-noir-spartan rounds
 # --------------------------------------------------------------------------------------------
 def prod_round_evals(polys, degree):

@@ -30,9 +30,7 @@ def _ser_vec(v):
 
 
 def _ser_g1(pt):
-    if pt is None:
-        return b"\x00" * 63 + b"\x40"
-    return pt[0].to_bytes(32, "little") + pt[1].to_bytes(32, "little")
+    return O.ser_g1(pt)
 
 
 def eq_le(r):

@@ -152,18 +152,25 @@ def test_msm_repeated_bases_take_the_exception_path(cozk, ctx):
     assert got == O.g1_mul(g, sum(flags) % O.R)
 
 
+def test_prf_stream_matches_oracle(cozk, ctx):
+    """cozk_vec_fill_prf: element j = one ChaCha12 block keyed with the 32-byte key (csrc/prf.cuh) == pyref.prf_fr;
+    257 elements cover both halves of a block and the second-attempt path (6 % of the draws)"""
+    key = O.harness_prf_key(11, 3)
+    for ctr in (0, 12345, (1 << 33) + 7):
+        assert cozk.Vec.prf(ctx, 257, key, counter=ctr).to_ints() == O.prf_fr_vec(key, ctr, 257)
+
+
 def test_rep3_share_vec_matches_oracle_sharing(cozk, ctx):
-    """witness scatter on the device: party p's (a, b) of rep3::share_field_element with t0 = stream(seed0),
-    t1 = stream(seed1); the three a components open to the secret, and b is the previous party's a"""
+    """witness scatter on the device: party p's (a, b) of rep3::share_field_element with t0 = PRF(key0, .),
+    t1 = PRF(key1, .); the three a components open to the secret, and b is the previous party's a"""
     n = 257
     v = O.synthetic_fr(4040, n)
     V = cozk.Vec.from_ints(ctx, v)
-    t0, t1 = O.synthetic_fr(51, n), O.synthetic_fr(52, n)
-    t2 = [(x - y - z) % O.R for x, y, z in zip(v, t0, t1)]
-    exp = [(t0, t2), (t1, t0), (t2, t1)]
+    k0, k1 = O.harness_prf_key(51, 0), O.harness_prf_key(52, 0)
+    exp = O.rep3_share_vec(v, k0, k1, counter=9)
     got = []
     for p in range(3):
-        a, b = V.rep3_share(51, 52, p)
+        a, b = V.rep3_share(k0, k1, p, counter=9)
         got.append((a.to_ints(), b.to_ints()))
-        assert got[p] == exp[p]
+        assert got[p] == ([x[0] for x in exp[p]], [x[1] for x in exp[p]])
     assert [(x + y + z) % O.R for x, y, z in zip(got[0][0], got[1][0], got[2][0])] == v

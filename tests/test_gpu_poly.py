@@ -174,12 +174,14 @@ def test_layer_round_fused_equals_separate_calls(cozk, ctx, mode, length):
     assert fused.coeffs() == sep.coeffs()
 
 
+@pytest.mark.parametrize("resident", [True, False])
 @pytest.mark.parametrize("mode", ["rep3", "plain"])
 @pytest.mark.parametrize("length", [4, 6, 96, 2048, 4096 + 8, 1 << 14])
-def test_layer_prove_rounds_matches_separate_calls(cozk, ctx, mode, length):
-    """cozk_layer_prove_rounds (whole round loop behind the ABI; per-round launches above 2048 elements, then the
-    resident mailbox kernel down to the final claims) sends the same round polynomials and ends in the same final
-    claims as compute_cubic / bind / final_claims called one by one"""
+def test_layer_prove_rounds_matches_separate_calls(cozk, ctx, mode, length, resident):
+    """cozk_layer_prove_rounds (whole round loop behind the ABI; per-round launches above 2048 elements, then -- with
+    resident rounds on -- the resident mailbox kernel down to the final claims) sends the same round polynomials and
+    ends in the same final claims as compute_cubic / bind / final_claims called one by one"""
+    ctx.set_resident_rounds(resident)
     rng = O.SplitMix64(length * 7 + (mode == "plain"))
     coeffs = _shares(rng, length, mode)
     nodes = (length + 1) // 2
@@ -204,12 +206,106 @@ def test_layer_prove_rounds_matches_separate_calls(cozk, ctx, mode, length):
         seen.append(cf)
         return rs[rnd], claims[rnd]
 
-    got_r, (left, right) = one.prove_rounds(eq_o, claim0, nv, exchange)
+    try:
+        got_r, (left, right) = one.prove_rounds(eq_o, claim0, nv, exchange)
+    finally:
+        ctx.set_resident_rounds(None)
     assert seen == expected
     assert got_r == rs
     if nv:
         assert (left, right) == sep.final_claims()
         assert one.coeffs() == sep.coeffs()
+
+
+def test_resident_watchdog_falls_back_to_per_round_launches(cozk, ctx, monkeypatch):
+    """a round callback slower than the resident kernel's watchdog (COZK_RESIDENT_TIMEOUT_S) used to fail the proof
+    ("the resident kernel gave up waiting for the host"); now the remaining rounds of the call run as one launch per
+    round from the state the kernel left: same round polynomials, same final claims.  The stall is put in the middle of
+    the resident tail and again in its last round (the kernel then leaves before its final bind)."""
+    import time
+    monkeypatch.setenv("COZK_RESIDENT_TIMEOUT_S", "1")
+    rng = O.SplitMix64(4242)
+    length = 512
+    coeffs = _shares(rng, length, "rep3")
+    nv = 8
+    w = [rng.field() for _ in range(nv)]
+    claim0 = rng.field()
+    rs = [rng.field() for _ in range(nv)]
+    claims = [rng.field() for _ in range(nv)]
+    sep = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+    eq_s = cozk.SplitEqPolynomial(ctx, w)
+    expected, c = [], claim0
+    for j in range(nv):
+        expected.append(sep.compute_cubic(eq_s, c))
+        sep.bind(rs[j])
+        eq_s.bind(rs[j])
+        c = claims[j]
+    for stall_round in (3, nv - 1):
+        one = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
+        eq_o = cozk.SplitEqPolynomial(ctx, w)
+        seen = []
+
+        def exchange(rnd, cf):
+            seen.append(cf)
+            if rnd == stall_round:
+                time.sleep(1.6)
+            return rs[rnd], claims[rnd]
+
+        ctx.set_resident_rounds(True)
+        try:
+            got_r, (left, right) = one.prove_rounds(eq_o, claim0, nv, exchange)
+        finally:
+            ctx.set_resident_rounds(None)
+        assert seen == expected and got_r == rs
+        assert (left, right) == sep.final_claims()
+        assert one.coeffs() == sep.coeffs()
+
+
+def test_two_interdependent_contexts_default_flags(cozk):
+    """the failure of round 1's suite logs, designed out: two provers in ONE process on ONE GPU that need each other's
+    round messages (each callback waits at a barrier until the other prover has sent its round polynomial), both
+    contexts created with DEFAULT flags.  The automatic default keeps resident round kernels off as soon as a second
+    context lives on the device, so neither prover blocks the other's launches; both finish with the same transcript."""
+    import threading
+    n_prov = 2
+    ctxs = [cozk.Context(0) for _ in range(n_prov)]
+    rng = O.SplitMix64(2718)
+    length, nv = 1024, 9
+    coeffs = _shares(rng, length, "plain")
+    w = [rng.field() for _ in range(nv)]
+    claim0 = rng.field()
+    rs = [rng.field() for _ in range(nv)]
+    claims = [rng.field() for _ in range(nv)]
+    barrier = threading.Barrier(n_prov, timeout=60)
+    seen = [[] for _ in range(n_prov)]
+    results, errors = [None] * n_prov, []
+
+    def run(i):
+        try:
+            layer = cozk.Rep3DenseInterleavedPolynomial.new(ctxs[i], coeffs)
+            eq = cozk.SplitEqPolynomial(ctxs[i], w)
+
+            def exchange(rnd, cf):
+                seen[i].append(cf)
+                barrier.wait()  # the "coordinator" answers only when every prover's message of this round is in
+                return rs[rnd], claims[rnd]
+
+            results[i] = layer.prove_rounds(eq, claim0, nv, exchange)
+        except Exception as e:  # noqa: BLE001 - reported below
+            errors.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=run, args=(i,)) for i in range(n_prov)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not errors, errors
+    assert all(not t.is_alive() for t in th)
+    assert seen[0] == seen[1] and len(seen[0]) == nv
+    assert results[0] == results[1] and results[0][0] == rs
+    for c in ctxs:
+        c.close()
 
 
 @pytest.mark.parametrize("mode", ["rep3", "plain"])
@@ -220,10 +316,10 @@ def test_layer_output_local_masks_and_claimed_outputs(cozk, ctx, mode):
     plain = layer.layer_output_local().to_ints()
     assert plain == O.interleaved_layer_output_local(coeffs)
     assert layer.claimed_outputs() == O.interleaved_layer_output_local(coeffs)
-    # masked: mask_j = PRF(seed_self, ctr + j) - PRF(seed_prev, ctr + j)
-    got = layer.layer_output_local(masked=True, seed_self=11, seed_prev=22, counter=5).to_ints()
-    ms = O.synthetic_fr(11, 40)[5:5 + 32]
-    mp = O.synthetic_fr(22, 40)[5:5 + 32]
+    # masked: mask_j = PRF(key_self, ctr + j) - PRF(key_prev, ctr + j)  (keyed ChaCha12, csrc/prf.cuh)
+    ks, kp = O.harness_prf_key(11, 0), O.harness_prf_key(22, 0)
+    got = layer.layer_output_local(masked=True, key_self=ks, key_prev=kp, counter=5).to_ints()
+    ms, mp = O.prf_fr_vec(ks, 5, 32), O.prf_fr_vec(kp, 5, 32)
     assert got == [(v + a - b) % O.R for v, a, b in zip(plain, ms, mp)]
 
 
@@ -234,13 +330,42 @@ def test_rep3_layer_output_reconstructs_product(cozk, ctx):
     n = 128
     vals = [rng.field() for _ in range(n)]
     sh = [O.rep3_share(v, rng) for v in vals]
-    seeds = [101, 202, 303]  # seed_i is shared between party i and party i+1
+    seeds = [O.harness_prf_key(101, p) for p in range(3)]  # key_i is shared between party i and party i+1
     ca = []
     for p in range(3):
         layer = cozk.Rep3DenseInterleavedPolynomial.new(ctx, [s[p] for s in sh])
-        ca.append(layer.layer_output_local(masked=True, seed_self=seeds[p], seed_prev=seeds[(p + 2) % 3], counter=0).to_ints())
+        ca.append(layer.layer_output_local(masked=True, key_self=seeds[p], key_prev=seeds[(p + 2) % 3], counter=0).to_ints())
     recon = [(ca[0][j] + ca[1][j] + ca[2][j]) % O.R for j in range(n // 2)]
     assert recon == [vals[2 * j] * vals[2 * j + 1] % O.R for j in range(n // 2)]
+
+
+@pytest.mark.parametrize("n", [1, 2, 255, 1024])
+def test_rep3_mul_vec_local_matches_oracle(cozk, ctx, n):
+    """cozk_rep3_mul_vec_local (the generic rep3::arithmetic::mul_vec, local half) against the oracle: every party's
+    c.a = a.a*b.a + a.a*b.b + a.b*b.a (mpc-types/src/protocols/rep3/arithmetic/ops.rs:71-78) + its zero-sharing
+    mask; after the ring reshare (b = previous party's a) the result is exactly O.rep3_mul_vec, which opens to the
+    element-wise product; the plain mode is the plain product"""
+    rng = O.SplitMix64(900 + n)
+    xs, ys = [rng.field() for _ in range(n)], [rng.field() for _ in range(n)]
+    X, Y = [O.rep3_share(v, rng) for v in xs], [O.rep3_share(v, rng) for v in ys]
+    keys = [O.harness_prf_key(77, p) for p in range(3)]
+    ctr = 40
+    prf = [O.prf_fr_vec(keys[p], ctr, n) for p in range(3)]
+    masks = [[(prf[p][j] - prf[(p + 2) % 3][j]) % O.R for j in range(n)] for p in range(3)]
+    exp = O.rep3_mul_vec([[s[p] for s in X] for p in range(3)], [[s[p] for s in Y] for p in range(3)], masks)
+    ca = []
+    for p in range(3):
+        xa, xb = cozk.Vec.from_ints(ctx, [s[p][0] for s in X]), cozk.Vec.from_ints(ctx, [s[p][1] for s in X])
+        ya, yb = cozk.Vec.from_ints(ctx, [s[p][0] for s in Y]), cozk.Vec.from_ints(ctx, [s[p][1] for s in Y])
+        unmasked = cozk.rep3_mul_vec_local(ctx, xa, xb, ya, yb).to_ints()
+        assert unmasked == [O.rep3_local_mul(X[j][p], Y[j][p]) for j in range(n)]
+        ca.append(cozk.rep3_mul_vec_local(ctx, xa, xb, ya, yb, key_self=keys[p], key_prev=keys[(p + 2) % 3], counter=ctr).to_ints())
+        assert ca[p] == [e[0] for e in exp[p]]
+    got = [[(ca[p][j], ca[(p + 2) % 3][j]) for j in range(n)] for p in range(3)]  # the ring reshare
+    assert got == exp
+    assert [O.rep3_open([got[p][j] for p in range(3)]) for j in range(n)] == [x * y % O.R for x, y in zip(xs, ys)]
+    pl = cozk.rep3_mul_vec_local(ctx, cozk.Vec.from_ints(ctx, xs), None, cozk.Vec.from_ints(ctx, ys), None).to_ints()
+    assert pl == [x * y % O.R for x, y in zip(xs, ys)]
 
 
 def test_open_quadratic_and_pst_fold(cozk, ctx):

@@ -43,6 +43,30 @@ def test_reference_constants():
     assert O.g1_mul(O.G1_GEN, O.R) is None and O.g1_mul(O.G1_GEN, O.R - 1) == O.g1_neg(O.G1_GEN)
 
 
+def test_chacha_block_rfc8439_vector_and_prf():
+    """the keyed PRF behind every share / mask (csrc/prf.cuh) is the ChaCha block function; pin the restatement
+    with the RFC 8439 section 2.3.2 block test vector (20 rounds: key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:
+    00:00:00:00), then check the 12-round PRF: C restatement == Python restatement, range, determinism, zero-sum masks"""
+    key = bytes(range(32))
+    st = O._CHACHA_CONST + [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)] + [1, 0x09000000, 0x4A000000, 0]
+    assert O.chacha_block_words(st, 20) == [
+        0xe4e7f110, 0x15593bd1, 0x1fdd0f50, 0xc47120a3, 0xc7f4d1c7, 0x0368c033, 0x9aaa2204, 0x4e6cd4c3,
+        0x466482d2, 0x09aa9f07, 0x05d7c214, 0xa2028bd9, 0xd19c12b5, 0xb94e16de, 0xe883d0cb, 0x4e3c50a2]
+    k1, k2 = O.harness_prf_key(7, 0), O.harness_prf_key(7, 1)
+    assert len(k1) == 32 and k1 != k2
+    v = O.prf_fr_vec(k1, 1000, 200)
+    assert all(0 <= x < O.R for x in v) and len(set(v)) == 200
+    assert v[5:10] == O.prf_fr_vec(k1, 1005, 5) and v != O.prf_fr_vec(k2, 1000, 200)
+    assert _ints(coracle.prf_fr(k1, 1000, 200), O.R) == v
+    # a counter beyond 32 bits reaches the high counter word
+    assert _ints(coracle.prf_fr(k2, (1 << 40) + 3, 4), O.R) == O.prf_fr_vec(k2, (1 << 40) + 3, 4)
+    # rep3_share_vec: the a components open to the secret, b is the previous party's a
+    sec = O.synthetic_fr(9, 17)
+    sh = O.rep3_share_vec(sec, k1, k2, counter=3)
+    assert [(sh[0][i][0] + sh[1][i][0] + sh[2][i][0]) % O.R for i in range(17)] == sec
+    assert all(sh[p][i][1] == sh[(p + 2) % 3][i][0] for p in range(3) for i in range(17))
+
+
 def test_rep3_identities():
     rng = O.SplitMix64(3)
     x, y = rng.field(), rng.field()

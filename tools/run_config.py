@@ -82,6 +82,6 @@ print(json.dumps({"config": args.config, **{k: v for k, v in kw.items()}, "devic
                   "ms_per_proof": round(dt * 1e3, 2), "cycles_per_s": round((1 << kw["log_n"]) / dt, 1),
                   "phases_ms": {"commit": round(r.t_commit_ms, 2), "gp_construct": round(r.t_gp_construct_ms, 2),
                                 "gp_prove": round(r.t_gp_prove_ms, 2), "evaluate": round(r.t_eval_ms, 2), "open": round(r.t_open_ms, 2)},
-                  "ring_bytes_per_party": int(r.bytes_ring), "star_messages": int(r.star_messages), "proof_bytes": int(r.proof_len),
+                  "ring_bytes_all_parties": int(r.bytes_ring), "star_messages": int(r.star_messages), "proof_bytes": int(r.proof_len),
                   "setup_s": round(setup_s, 1), "hbm_gib_in_use": round((torch.cuda.mem_get_info(0)[1] - torch.cuda.mem_get_info(0)[0]) / 2**30, 1)}), flush=True)
 h.close()
