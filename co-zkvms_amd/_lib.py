@@ -132,6 +132,8 @@ SIGNATURES = {
     "cozk_spliteq_bind": (_i, [_vp, _vp, _vp]),
     "cozk_prof_enable": (_i, [_vp, _i]),
     "cozk_prof_read": (_i, [_vp, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64), ctypes.POINTER(_u64)]),
+    "cozk_prof_kernel_name": (ctypes.c_char_p, [_i]),
+    "cozk_prof_read_kernel": (_i, [_vp, _i, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "cozk_layer_as_poly": (_i, [_vp, _vp, _pp]),
     "cozk_wire_g1_encode": (_i, [_vp, _i, _vp]),
     "cozk_wire_g1_decode": (_i, [_vp, _vp, ctypes.POINTER(_i)]),

@@ -153,6 +153,7 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
         (void)hipEventDestroy(pr.first);
         (void)hipEventDestroy(pr.second);
     }
+    for (ProfSlot& sl : ctx->prof_slots) sl.reset();
     ctx->msm_ws.release();
     ctx->scratch.release();
     ctx->scratch2.release();

@@ -146,6 +146,31 @@ struct DevPool {
     }
 };
 
+// HIP-event timing of named kernels for bench.py's per-kernel roofline entries (cozk_prof_read_kernel): a slot
+// accumulates launches, elapsed ms on the context's stream and the ALGORITHMIC bytes of those launches
+enum {
+    COZK_PROF_EVAL_CHI = 0,   // k_poly_eval_chi
+    COZK_PROF_LINCOMB,        // k_poly_lincomb
+    COZK_PROF_BIND_CUBIC,     // k_layer_bind_cubic
+    COZK_PROF_MSM_SCATTER,    // k_msm_scatter_lds
+    COZK_PROF_LAYER_OUTPUT,   // k_layer_output (mul_vec local half)
+    COZK_PROF_SLOTS
+};
+struct ProfSlot {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+    double ms = 0.0;
+    uint64_t launches = 0, alg_bytes = 0;
+    void reset() {
+        for (auto& pr : events) {
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        events.clear();
+        ms = 0.0;
+        launches = alg_bytes = 0;
+    }
+};
+
 struct cozk_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -169,6 +194,30 @@ struct cozk_ctx {
     uint64_t prof_launches = 0;
     uint64_t prof_units = 0;  // point additions issued by those launches
     uint64_t prof_alg_bytes = 0;  // algorithmic bytes of those launches: n * (64 B base + scalar bytes) per MSM
+    ProfSlot prof_slots[COZK_PROF_SLOTS];
+};
+
+// brackets ONE kernel launch with a pair of events on `st` while profiling is enabled (no-op otherwise)
+struct ProfScope {
+    cozk_ctx* ctx;
+    hipStream_t st;
+    int slot;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProfScope(cozk_ctx* c, int slot_, uint64_t alg_bytes, hipStream_t stream = nullptr) : ctx(c), st(stream ? stream : c->stream), slot(slot_) {
+        if (!ctx->prof_enabled) return;
+        if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) {
+            e0 = e1 = nullptr;
+            return;
+        }
+        (void)hipEventRecord(e0, st);
+        ctx->prof_slots[slot].launches += 1;
+        ctx->prof_slots[slot].alg_bytes += alg_bytes;
+    }
+    ~ProfScope() {
+        if (!e0) return;
+        (void)hipEventRecord(e1, st);
+        ctx->prof_slots[slot].events.push_back({e0, e1});
+    }
 };
 
 struct cozk_bases {

@@ -825,6 +825,14 @@ static void msm_sort(cozk_ctx* ctx, hipStream_t st, MsmSortWs& sw, const MsmSetP
         msm_scan(st, bsums, nb, false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
+            // algorithmic bytes of the placement: every scalar read once + one 4-byte reference written per 16-bit window
+            uint64_t alg = 0;
+            for (uint32_t q = 0; q < r.second.second; q++) {
+                const MsmPolyDesc& d = h_descs[r.second.first + q];
+                const uint64_t sb = scalar_kind_bytes(r.first);
+                alg += (uint64_t)d.n * (sb + 4ull * ((sb * 8 + 15) / 16));
+            }
+            ProfScope prof(ctx, COZK_PROF_MSM_SCATTER, alg, st);
             KIND_DISPATCH(r.first, (k_msm_scatter_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist, refs, (uint32_t)bases->n)));
         }
     } else {
@@ -1253,6 +1261,30 @@ int cozk_prof_enable(cozk_ctx* ctx, int on) {
         ctx->prof_launches = 0;
         ctx->prof_units = 0;
         ctx->prof_alg_bytes = 0;
+        for (ProfSlot& sl : ctx->prof_slots) sl.reset();
+    });
+}
+
+static const char* const PROF_KERNEL_NAMES[COZK_PROF_SLOTS] = {"k_poly_eval_chi", "k_poly_lincomb", "k_layer_bind_cubic", "k_msm_scatter_lds",
+                                                               "k_layer_output"};
+const char* cozk_prof_kernel_name(int slot) { return slot >= 0 && slot < COZK_PROF_SLOTS ? PROF_KERNEL_NAMES[slot] : nullptr; }
+int cozk_prof_read_kernel(cozk_ctx* ctx, int slot, uint64_t* launches, double* total_ms, uint64_t* alg_bytes) {
+    return cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && slot >= 0 && slot < COZK_PROF_SLOTS, "prof_read_kernel: bad slot");
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        if (ctx->stream2) HIP_TRY(hipStreamSynchronize(ctx->stream2));
+        ProfSlot& sl = ctx->prof_slots[slot];
+        for (auto& pr : sl.events) {
+            float ms = 0;
+            HIP_TRY(hipEventElapsedTime(&ms, pr.first, pr.second));
+            sl.ms += ms;
+            (void)hipEventDestroy(pr.first);
+            (void)hipEventDestroy(pr.second);
+        }
+        sl.events.clear();
+        if (launches) *launches = sl.launches;
+        if (total_ms) *total_ms = sl.ms;
+        if (alg_bytes) *alg_bytes = sl.alg_bytes;
     });
 }
 

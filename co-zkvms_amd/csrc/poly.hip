@@ -1238,8 +1238,14 @@ int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys
         HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
         dim3 grid(gx, (unsigned)k);
-        if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
-        else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+        {
+            // algorithmic bytes: chi read once for the batch, every polynomial once (96 n, then 64 n per extra polynomial: SURVEY 8d K6)
+            uint64_t alg = (uint64_t)chi->n * 32;
+            for (size_t i = 0; i < k; i++) alg += (uint64_t)hl[i] * (mode == COZK_MODE_REP3 ? 64 : 32);
+            ProfScope prof(ctx, COZK_PROF_EVAL_CHI, alg);
+            if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+            else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+        }
         k_finish_sums<<<(unsigned)k, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
         HIP_TRY(hipGetLastError());
         std::vector<fe> h(k);
@@ -1323,8 +1329,14 @@ int cozk_poly_linear_combination(cozk_ctx* ctx, const cozk_poly* const* polys, c
         HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dc, hc.data(), k * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-        if (out_mode == COZK_MODE_REP3) k_poly_lincomb<2><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
-        else k_poly_lincomb<1><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
+        {
+            // algorithmic bytes: every operand component read once + the result written once ((m + 1) n S)
+            uint64_t alg = (uint64_t)maxlen * (out_mode == COZK_MODE_REP3 ? 64 : 32);
+            for (size_t i = 0; i < k; i++) alg += (uint64_t)hl[i] * ((ha[i] ? 32 : 0) + (out_mode == COZK_MODE_REP3 && hb[i] ? 32 : 0));
+            ProfScope prof(ctx, COZK_PROF_LINCOMB, alg);
+            if (out_mode == COZK_MODE_REP3) k_poly_lincomb<2><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
+            else k_poly_lincomb<1><<<grid_for(maxlen), PT, 0, ctx->stream>>>(da, db, dl, dc, (int)k, o->a0, o->b0, maxlen);
+        }
         HIP_TRY(hipGetLastError());
         *out = o;
     });
@@ -1900,12 +1912,17 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
             const fe* E1 = e->E1[e->c1];
             const fe* E2 = e->E2[e->c2];
             bool nested = e->E1_len != 1;
+            {
+            // algorithmic bytes: the layer read once and its bound half written once (SURVEY 8d K3 + K4 fused), + the eq tables
+            const uint64_t S = l->mode == COZK_MODE_REP3 ? 64 : 32;
+            ProfScope prof(ctx, COZK_PROF_BIND_CUBIC, (uint64_t)l->len * S + (uint64_t)nout * S + (uint64_t)(e->E1_len + e->E2_len) * 32);
             if (l->mode == COZK_MODE_REP3) {
                 if (nested) k_layer_bind_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
                 else k_layer_bind_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, 0, E2, e->E2_len, partial);
             } else {
                 if (nested) k_layer_bind_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
                 else k_layer_bind_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, rr, E1, 0, E2, e->E2_len, partial);
+            }
             }
             k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
             HIP_TRY(hipGetLastError());
@@ -2208,8 +2225,12 @@ int cozk_layer_output_local(cozk_ctx* ctx, const cozk_layer* l, int masked, cons
         fe* d = dev_alloc_fe(n);
         const fe* a = l->buf[l->cur][0];
         const fe* b = l->buf[l->cur][1];
-        if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
-        else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
+        {
+            // algorithmic bytes: 2 n shares read, n additive shares written (192 n for Rep3)
+            ProfScope prof(ctx, COZK_PROF_LAYER_OUTPUT, (uint64_t)l->len * (l->mode == COZK_MODE_REP3 ? 64 : 32) + (uint64_t)n * 32);
+            if (l->mode == COZK_MODE_REP3) k_layer_output<2><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
+            else k_layer_output<1><<<grid_for(n), PT, 0, ctx->stream>>>(a, b, l->len, d, n, masked, seed_self, seed_prev, counter);
+        }
         HIP_TRY(hipGetLastError());
         *out = new cozk_vec{ctx, n, COZK_SCALAR_FR, d, n * sizeof(fe), true};
     });

@@ -17,19 +17,34 @@ class Group:
         self.torch = torch
         self.dist = dist
         self.rank, self.local_rank, self.world = env_world()
-        # COZK_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box): the tiny
-        # collectives then run on CPU tensors while the proving still happens on the GPU
-        backend = backend or os.environ.get("COZK_DIST_BACKEND") or None
+        # The control plane (the barriers around the timed region, max-over-ranks, the digest gather) is a handful of
+        # 8..32-byte collectives: it runs on gloo / CPU tensors by default, so that several ranks may share one GPU
+        # (rehearsal on a 1-GPU box) and the bench does not depend on a collective library for work that has no bulk
+        # exchange (the worker axis: DESIGN.md 6).  COZK_DIST_BACKEND=nccl puts it on RCCL (needs one GPU per rank);
+        # the bulk Rep3 ring is RCCL inside libcozk either way (cozk_ring_*).
+        backend = backend or os.environ.get("COZK_DIST_BACKEND") or "gloo"
+        if backend == "nccl" and device is not None and self.world > torch.cuda.device_count():
+            backend = "gloo"  # RCCL refuses two ranks of one communicator on the same GPU
+        self.backend = backend
         self.device = device
         self.cuda = device is not None and backend != "gloo"
         self.sync_device = device
+        self._cpu_group = None
         if self.world > 1 and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-            dist.init_process_group(backend=backend or ("nccl" if self.cuda else "gloo"), rank=self.rank, world_size=self.world)
+            dist.init_process_group(backend=backend, rank=self.rank, world_size=self.world)
 
     def _dev(self):
         return self.torch.device("cuda", self.device) if self.cuda else self.torch.device("cpu")
+
+    def cpu_group(self):
+        """a gloo group over all ranks for host-side byte exchanges (None = the default group when that is gloo already)"""
+        if self.world == 1 or self.backend == "gloo":
+            return None
+        if self._cpu_group is None:
+            self._cpu_group = self.dist.new_group(backend="gloo")
+        return self._cpu_group
 
     def barrier(self):
         if self.sync_device is not None:

@@ -469,6 +469,11 @@ int cozk_spartan_proof_bytes(const cozk_spartan* h, uint8_t* out, size_t cap);
 int cozk_prof_enable(cozk_ctx* ctx, int on);
 int cozk_prof_read(cozk_ctx* ctx, uint64_t* launches, double* total_ms, uint64_t* point_adds,
                    uint64_t* alg_bytes);
+/* the same for the HBM-bound kernels of the polynomial seam: slot 0 k_poly_eval_chi, 1 k_poly_lincomb,
+ * 2 k_layer_bind_cubic, 3 k_msm_scatter_lds, 4 k_layer_output (cozk_prof_kernel_name; NULL past the last slot);
+ * alg_bytes = the algorithmic bytes of SURVEY.md 8d for those launches (stated per kernel in DESIGN.md 4) */
+const char* cozk_prof_kernel_name(int slot);
+int cozk_prof_read_kernel(cozk_ctx* ctx, int slot, uint64_t* launches, double* total_ms, uint64_t* alg_bytes);
 /* Fq Montgomery-multiply micro-benchmark: `iters` dependent products per lane on `lanes` lanes;
  * returns elapsed ms (HIP events) -- the measured integer-ALU peak. */
 int cozk_bench_montmul(cozk_ctx* ctx, size_t lanes, int iters, int variant, double* out_ms);

@@ -605,16 +605,25 @@ int orc_pipeline(const orc_config* cfg, orc_result* res, uint8_t* proof_out, siz
     bytes proof = {0, 0, 0};
     /* ---- 1. commit (every party MSMs every polynomial; shared: sum of parties; public: P0's) */
     g1a* cm = (g1a*)malloc(sizeof(g1a) * (size_t)(K + cfg->n_small + 1));
-    for (int i = 0; i < K + cfg->n_small; i++) {
-        const wpoly* p = i < K ? &polys[i] : &small[i - K];
-        g1j acc; g1j_identity(&acc);
-        g1a first;
-        for (int q = 0; q < np; q++) {
-            g1a c; commit_poly(srs, p, q, &c);
-            if (q == 0) first = c;
-            g1j_add_affine(&acc, &acc, &c);
+    /* batch_msm on the CPU is rayon over the polynomials, each an independent MSM (jolt-core batch_msm):
+     * one (polynomial, party) MSM per thread; the window-level loops inside msm_core then run serially (nested
+     * parallelism is off), which is what keeps all host cores busy when there are more polynomials than windows */
+    {
+        int total = (K + cfg->n_small) * np;
+        g1a* parts = (g1a*)malloc(sizeof(g1a) * (size_t)total);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int t = 0; t < total; t++) {
+            int i = t / np, q = t % np;
+            const wpoly* p = i < K ? &polys[i] : &small[i - K];
+            commit_poly(srs, p, q, &parts[t]);
         }
-        if (p->is_public) cm[i] = first; else g1j_to_affine(&cm[i], &acc);
+        for (int i = 0; i < K + cfg->n_small; i++) {
+            const wpoly* p = i < K ? &polys[i] : &small[i - K];
+            g1j acc; g1j_identity(&acc);
+            for (int q = 0; q < np; q++) g1j_add_affine(&acc, &acc, &parts[i * np + q]);
+            if (p->is_public) cm[i] = parts[i * np]; else g1j_to_affine(&cm[i], &acc);
+        }
+        free(parts);
     }
     for (int i = 0; i < K + cfg->n_small; i++) tr_point(&tr, &cm[i]);
     by_u64(&proof, (uint64_t)K);

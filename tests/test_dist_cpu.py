@@ -37,3 +37,37 @@ def test_gloo_world2(tmp_path):
         out, _ = p.communicate(timeout=240)
         assert p.returncode == 0, out.decode()
         assert b"ok" in out
+
+
+def test_bench_self_launch_two_ranks():
+    """`python bench.py --gpus 2` without a launcher starts its own two rank processes (fresh children, before anything
+    touches a GPU), they rendezvous over gloo on 127.0.0.1 and the parent relays exactly rank 0's JSON line"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 0, p.stderr.decode()
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["ranks_seen"] == [0, 1] and out["max_over_ranks"] == 2.0
+
+
+def test_bench_self_launch_reports_a_failed_rank():
+    """a rank that fails (here: no GPU for the proving) makes the parent exit non-zero instead of hanging or printing a line"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    try:
+        import torch
+        if torch.cuda.is_available():
+            import pytest
+            pytest.skip("a GPU is visible: the ranks would really prove")
+    except ImportError:
+        pass
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], env=env, capture_output=True, timeout=300)
+    assert p.returncode != 0
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
+def test_bench_rejects_world_size_mismatch():
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing-only"], env=env, capture_output=True, timeout=120)
+    assert p.returncode != 0 and b"WORLD_SIZE" in p.stderr
