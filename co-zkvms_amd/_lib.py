@@ -135,6 +135,13 @@ SIGNATURES = {
     "cozk_prof_kernel_name": (ctypes.c_char_p, [_i]),
     "cozk_prof_read_kernel": (_i, [_vp, _i, ctypes.POINTER(_u64), ctypes.POINTER(ctypes.c_double), ctypes.POINTER(_u64)]),
     "cozk_layer_as_poly": (_i, [_vp, _vp, _pp]),
+    "cozk_ring_unique_id": (_i, [_vp]),
+    "cozk_ring_init": (_i, [_vp, ctypes.c_char_p, _i, _i]),
+    "cozk_ring_destroy": (_i, [_vp]),
+    "cozk_ring_info": (_i, [_vp, ctypes.POINTER(_i), ctypes.POINTER(_i), ctypes.POINTER(_u64)]),
+    "cozk_reshare": (_i, [_vp, _vp, _vp]),
+    "cozk_rep3_mul_vec": (_i, [_vp, _vp, _vp, _vp, _vp, ctypes.c_char_p, ctypes.c_char_p, _u64, _pp, _pp]),
+    "cozk_ring_net_native": (_i, [_vp, _vp]),
     "cozk_wire_g1_encode": (_i, [_vp, _i, _vp]),
     "cozk_wire_g1_decode": (_i, [_vp, _vp, ctypes.POINTER(_i)]),
     "cozk_bench_montmul": (_i, [_vp, _sz, _i, _i, ctypes.POINTER(ctypes.c_double)]),

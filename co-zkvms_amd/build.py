@@ -6,7 +6,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcozk.so")
-SOURCES = ["capi.hip", "msm.hip", "poly.hip", "harness.hip", "shm_hub.hip"]
+SOURCES = ["capi.hip", "msm.hip", "poly.hip", "harness.hip", "shm_hub.hip", "ring.hip"]
 HEADERS = ["ff.cuh", "prf.cuh", "ff_macc.inc", "ff_mul2.inc", "ec.cuh", "fq9.cuh", "fq9_consts.inc", "fq9_mac.inc", "fq9_mul.inc", "common.hpp", "poly.cuh", os.path.join("host", "wire.hpp"), os.path.join("host", "net.hpp"), os.path.join("host", "prover.hpp"), os.path.join("host", "split.hpp"), os.path.join("host", "split_harness.hpp"), os.path.join("host", "spartan_harness.hpp"), os.path.join("..", "..", "include", "cozk.h")]
 
 
@@ -35,7 +35,7 @@ def build(force=False, verbose=True):
         if p.wait() != 0:
             raise RuntimeError("hipcc failed: " + " ".join(cmd))
     if force or procs or _newer(OUT, objs):
-        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs
+        cmd = ["hipcc", "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT] + objs + ["-ldl"]
         if verbose:
             print(" ".join(cmd), flush=True)
         subprocess.check_call(cmd)

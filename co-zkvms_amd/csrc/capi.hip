@@ -148,6 +148,7 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
     }
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->ring_comm) (void)cozk_ring_destroy(ctx);
     ctx->pool.destroy();
     for (auto& pr : ctx->prof_events) {
         (void)hipEventDestroy(pr.first);

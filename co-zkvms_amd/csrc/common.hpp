@@ -195,6 +195,10 @@ struct cozk_ctx {
     uint64_t prof_units = 0;  // point additions issued by those launches
     uint64_t prof_alg_bytes = 0;  // algorithmic bytes of those launches: n * (64 B base + scalar bytes) per MSM
     ProfSlot prof_slots[COZK_PROF_SLOTS];
+    // native Rep3 ring (ring.hip): an ncclComm_t of ring_n ranks, this context being rank ring_rank
+    void* ring_comm = nullptr;
+    int ring_rank = 0, ring_n = 0;
+    uint64_t ring_bytes = 0;
 };
 
 // brackets ONE kernel launch with a pair of events on `st` while profiling is enabled (no-op otherwise)

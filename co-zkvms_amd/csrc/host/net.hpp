@@ -195,9 +195,11 @@ struct CallbackRingNet : RingNet {
     cozk_ring_net cb;
     explicit CallbackRingNet(const cozk_ring_net& c) : cb(c) {}
     void reshare(cozk_ctx* ctx, const fe* dev_send, fe* dev_recv, size_t n) override {
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        // a foreign transport reads dev_send from the host's side: the stream must have produced it; a stream-ordered
+        // one (the native RCCL ring) enqueues behind the producing kernels and nothing waits
+        if (!cb.stream_ordered) HIP_TRY(hipStreamSynchronize(ctx->stream));
         if (cb.reshare(cb.user, (const void*)dev_send, (void*)dev_recv, n * sizeof(fe)) != 0)
-            throw CozkError(COZK_ERR_INTERNAL, "ring reshare callback failed");
+            throw CozkError(COZK_ERR_INTERNAL, cb.stream_ordered ? std::string("ring reshare failed: ") + ctx->last_error : std::string("ring reshare callback failed"));
         bytes_sent += n * sizeof(fe);
     }
 };

@@ -109,6 +109,40 @@ class Context:
         default (on only while this is the one live context on its device in the process)"""
         self.check(self._l.cozk_ctx_set_resident_rounds(self.h, -1 if enable is None else (1 if enable else 0)))
 
+    # ---- native Rep3 ring over RCCL (cozk_ring_*): one party per GPU / process
+    @staticmethod
+    def ring_unique_id():
+        """128 opaque bytes for cozk_ring_init; ONE participant draws them, the host hands them to the others"""
+        buf = (ctypes.c_uint8 * 128)()
+        rc = L.lib().cozk_ring_unique_id(buf)
+        if rc != L.OK:
+            raise L.CozkError(rc, "cozk_ring_unique_id failed (librccl unavailable?)")
+        return bytes(buf)
+
+    def ring_init(self, ring_id, rank, nranks=3):
+        self.check(self._l.cozk_ring_init(self.h, bytes(ring_id), rank, nranks))
+
+    def ring_destroy(self):
+        self.check(self._l.cozk_ring_destroy(self.h))
+
+    def ring_info(self):
+        r, n, b = ctypes.c_int(), ctypes.c_int(), ctypes.c_uint64()
+        self.check(self._l.cozk_ring_info(self.h, ctypes.byref(r), ctypes.byref(n), ctypes.byref(b)))
+        return r.value, n.value, b.value
+
+    def reshare(self, send):
+        """send `send` to the next party, return what the previous party sent (cozk_reshare)"""
+        recv = Vec.alloc(self, len(send), L.SCALAR_FR)
+        self.check(self._l.cozk_reshare(self.h, send.h, recv.h))
+        return recv
+
+    def rep3_mul_vec(self, xa, xb, ya, yb, key_self, key_prev, counter=0):
+        """rep3::arithmetic::mul_vec, whole (local product + mask + ring exchange) -> (c.a, c.b) vectors"""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self.check(self._l.cozk_rep3_mul_vec(self.h, xa.h, xb.h, ya.h, yb.h, L.prf_key(key_self), L.prf_key(key_prev), counter,
+                                             ctypes.byref(a), ctypes.byref(b)))
+        return Vec(self, a, L.SCALAR_FR), Vec(self, b, L.SCALAR_FR)
+
     def close(self):
         if self.h:
             self._l.cozk_ctx_destroy(self.h)

@@ -25,10 +25,10 @@ class HubNet(ctypes.Structure):
 
 
 class RingNetC(ctypes.Structure):
-    _fields_ = [("user", ctypes.c_void_p), ("reshare", _RS)]
+    _fields_ = [("user", ctypes.c_void_p), ("reshare", _RS), ("stream_ordered", ctypes.c_int)]
 
 
-PARTY_SYMBOLS = ["cozk_shm_hub_open", "cozk_shm_hub_net", "cozk_shm_hub_unlink", "cozk_shm_hub_set_timeout_ms", "cozk_shm_hub_abort", "cozk_shm_hub_close",
+PARTY_SYMBOLS = ["cozk_ring_unique_id", "cozk_ring_init", "cozk_ring_destroy", "cozk_ring_net_native", "cozk_shm_hub_open", "cozk_shm_hub_net", "cozk_shm_hub_unlink", "cozk_shm_hub_set_timeout_ms", "cozk_shm_hub_abort", "cozk_shm_hub_close",
                  "cozk_harness_create_party", "cozk_harness_create_participant", "cozk_harness_prove_distributed", "cozk_copy"]
 
 
@@ -194,7 +194,40 @@ class TorchRing:
                 return 1
 
         self._cb = _RS(_rs)
-        self.net = RingNetC(None, self._cb)
+        self.net = RingNetC(None, self._cb, 0)
+
+
+class NativeRing:
+    """the Rep3 ring inside libcozk (csrc/ring.hip): ncclSend / ncclRecv on the party context's stream, GPU to GPU over
+    xGMI, nothing staged and nothing waited for on the host.  `ring_group`: the torch.distributed group (any backend; only
+    used to hand the 128-byte id from ring rank 0 to the others) whose ranks form THIS ring, in ring order."""
+
+    def __init__(self, ctx_handle, ring_rank, ring_size=3, ring_group=None):
+        self._l = L.lib()
+        self.ctx = ctx_handle
+        self.error = None
+        box = [None]
+        if ring_rank == 0:
+            buf = (ctypes.c_uint8 * 128)()
+            rc = self._l.cozk_ring_unique_id(buf)
+            if rc != L.OK:
+                raise L.CozkError(rc, "cozk_ring_unique_id failed (librccl unavailable?)")
+            box = [bytes(buf)]
+        if ring_size > 1:
+            src = dist.get_global_rank(ring_group, 0) if ring_group is not None else 0
+            dist.broadcast_object_list(box, src=src, group=ring_group)
+        rc = self._l.cozk_ring_init(ctx_handle, box[0], ring_rank, ring_size)
+        if rc != L.OK:
+            raise L.CozkError(rc, (self._l.cozk_last_error(ctx_handle) or b"cozk_ring_init failed").decode())
+        self.net = RingNetC()
+        rc = self._l.cozk_ring_net_native(ctx_handle, ctypes.byref(self.net))
+        if rc != L.OK:
+            raise L.CozkError(rc, "cozk_ring_net_native")
+
+    def close(self):
+        if self.ctx:
+            self._l.cozk_ring_destroy(self.ctx)
+            self.ctx = None
 
 
 class DistributedParty:

@@ -18,7 +18,7 @@ class StarNet(ctypes.Structure):
 
 
 class RingNet(ctypes.Structure):
-    _fields_ = [("user", ctypes.c_void_p), ("reshare", _RESHARE)]
+    _fields_ = [("user", ctypes.c_void_p), ("reshare", _RESHARE), ("stream_ordered", ctypes.c_int)]
 
 
 class WorkerParams(ctypes.Structure):

@@ -313,7 +313,33 @@ typedef struct cozk_star_net {
 typedef struct cozk_ring_net {
     void* user;
     int (*reshare)(void* user, const void* dev_send, void* dev_recv, size_t nbytes);
+    int stream_ordered; /* 0: libcozk synchronises the context's stream before the call and the callback returns when
+                           dev_recv is complete; 1: the callback only ENQUEUES the exchange on the context's stream
+                           (cozk_ctx_stream) -- no host synchronisation on either side (cozk_ring_net_native) */
 } cozk_ring_net;
+
+/* Native ring: the same exchange carried by RCCL inside libcozk -- one ncclSend (to the next party) / ncclRecv (from the
+ * previous one) pair per call on the context's stream, GPU to GPU over xGMI, asynchronous to the host.  One party per
+ * GPU / process.  Set-up mirrors ncclCommInitRank: ONE participant draws an id (cozk_ring_unique_id), the host
+ * distributes those 128 bytes through its own channel (the mpc-net connection it already has), every participant calls
+ * cozk_ring_init(ctx, id, rank, nranks) -- rank = PartyID, nranks = 3 for Rep3; the call blocks until all have joined.
+ * librccl is loaded on first use.  Replaces Rep3Network::{reshare, send_next, recv_prev} as used by
+ * mpc-core/src/protocols/rep3/arithmetic.rs:144-164. */
+#define COZK_RING_ID_BYTES 128
+int cozk_ring_unique_id(uint8_t out[COZK_RING_ID_BYTES]);
+int cozk_ring_init(cozk_ctx* ctx, const uint8_t id[COZK_RING_ID_BYTES], int rank, int nranks);
+int cozk_ring_destroy(cozk_ctx* ctx);
+int cozk_ring_info(cozk_ctx* ctx, int* rank, int* nranks, uint64_t* bytes_sent);
+/* reshare_additive_many (arithmetic.rs:152-164): send `send` to the next party, receive `recv` from the previous one */
+int cozk_reshare(cozk_ctx* ctx, const cozk_vec* send, cozk_vec* recv);
+/* rep3::arithmetic::mul_vec, whole: out_a = x (x) y + PRF(key_self, counter + j) - PRF(key_prev, counter + j) (local
+ * product, mpc-types/src/protocols/rep3/arithmetic/ops.rs:71-78, + zero-sharing mask), then the ring exchange:
+ * out_b = the previous party's out_a.  x, y as SoA component vectors; both outputs are new vectors. */
+int cozk_rep3_mul_vec(cozk_ctx* ctx, const cozk_vec* xa, const cozk_vec* xb, const cozk_vec* ya, const cozk_vec* yb,
+                      const uint8_t* key_self, const uint8_t* key_prev, uint64_t counter, cozk_vec** out_a,
+                      cozk_vec** out_b);
+/* a cozk_ring_net backed by the context's native ring, for the worker drivers and cozk_harness_prove_distributed */
+int cozk_ring_net_native(cozk_ctx* ctx, cozk_ring_net* out);
 
 /* ---------------------------------------------------------------- wire format -------------- */
 /* ark-serialize *uncompressed* G1Affine, the encoding of every point the workers send and of the proof structs
