@@ -300,6 +300,9 @@ static int cozk_guard(cozk_ctx* ctx, F&& f) {
     } cur(ctx);
     try {
         if (ctx) HIP_TRY(hipSetDevice(ctx->device));
+        // every entry point starts from a clean per-thread error state: a failed HIP call of the host's own (or of a
+        // library it uses -- RCCL probes capabilities with calls that fail benignly) must not surface in our launch checks
+        (void)hipGetLastError();
         f();
         return COZK_OK;
     } catch (const CozkError& e) {

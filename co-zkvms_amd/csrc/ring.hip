@@ -45,7 +45,7 @@ RcclApi& rccl() {
             if ((api.handle = dlopen(n, RTLD_NOW | RTLD_NOLOAD))) break;
         if (!api.handle)
             for (const char* n : names)
-                if ((api.handle = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+                if ((api.handle = dlopen(n, RTLD_NOW | RTLD_LOCAL))) break;
         if (!api.handle) {
             api.error = std::string("librccl not found: ") + (dlerror() ? dlerror() : "?");
             return;
@@ -92,6 +92,7 @@ void ring_exchange(cozk_ctx* ctx, const void* dev_send, void* dev_recv, size_t n
     ncclResult_t rg = a.GroupEnd();
     if (rs != ncclSuccess || rr != ncclSuccess) throw CozkError(COZK_ERR_INTERNAL, std::string("ring: ncclSend/ncclRecv failed: ") + a.GetErrorString(rs != ncclSuccess ? rs : rr));
     if (rg != ncclSuccess) throw CozkError(COZK_ERR_INTERNAL, std::string("ring: ncclGroupEnd failed: ") + a.GetErrorString(rg));
+    (void)hipGetLastError();  // RCCL probes capabilities with HIP calls that may fail benignly: never leave their error for our next launch check
     ctx->ring_bytes += nbytes;
 }
 
@@ -139,6 +140,8 @@ int cozk_ring_init(cozk_ctx* ctx, const uint8_t id_bytes[COZK_RING_ID_BYTES], in
         memcpy(id.internal, id_bytes, COZK_RING_ID_BYTES);
         ncclComm_t comm = nullptr;
         RCCL_TRY(a, a.CommInitRank(&comm, nranks, id, rank));  // blocks until every rank of the ring has called it
+        (void)hipGetLastError();  // (see ring_exchange)
+        HIP_TRY(hipSetDevice(ctx->device));
         ctx->ring_comm = comm;
         ctx->ring_rank = rank;
         ctx->ring_n = nranks;
@@ -154,7 +157,9 @@ int cozk_ring_destroy(cozk_ctx* ctx) {
         RcclApi& a = rccl_or_throw();
         ncclComm_t comm = (ncclComm_t)ctx->ring_comm;
         ctx->ring_comm = nullptr;
-        RCCL_TRY(a, a.CommDestroy(comm));
+        ncclResult_t r = a.CommDestroy(comm);
+        (void)hipGetLastError();
+        if (r != ncclSuccess) throw CozkError(COZK_ERR_INTERNAL, std::string("ncclCommDestroy failed: ") + a.GetErrorString(r));
     });
 }
 

@@ -12,6 +12,7 @@ import subprocess
 import sys
 
 import pytest
+import torch  # noqa: F401 - a torch host maps its own librccl first; libcozk then reuses that copy (one RCCL per process)
 
 import pyref as O
 
