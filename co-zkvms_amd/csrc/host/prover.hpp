@@ -447,6 +447,200 @@ static bool verify_grand_product(const GrandProductProof& proof, Transcript& tr,
     return true;
 }
 
+// ================================================================= toggled (sparse) batched grand product
+// Rep3ToggledBatchedGrandProduct (co-jolt/src/subprotocols/sparse_grand_product.rs:890-1020): one toggle layer (flags x
+// fingerprints) under tree_depth Rep3SparseInterleavedPolynomial layers.  The sparse layers are kept dense on the device
+// (toggle_layer.inc), so they are exactly a Rep3BatchedDenseGrandProduct over the toggle layer's output; the toggle layer
+// has its own round function and, unlike a multiplication layer, no r_layer fold after its sumcheck (:850-873).
+struct ToggleH {
+    cozk_toggle* h = nullptr;
+    ToggleH() {}
+    explicit ToggleH(cozk_toggle* t) : h(t) {}
+    ToggleH(const ToggleH&) = delete;
+    ToggleH& operator=(const ToggleH&) = delete;
+    ToggleH(ToggleH&& o) noexcept : h(o.h) { o.h = nullptr; }
+    ToggleH& operator=(ToggleH&& o) noexcept {
+        if (this != &o) {
+            cozk_toggle_free(h);
+            h = o.h;
+            o.h = nullptr;
+        }
+        return *this;
+    }
+    ~ToggleH() { cozk_toggle_free(h); }
+};
+
+struct Rep3ToggledBatchedGrandProduct {
+    ToggleH toggle_layer;
+    Rep3BatchedDenseGrandProduct sparse_layers;
+
+    // construct (sparse_grand_product.rs:905-930): sparse_layers[0] = toggle_layer.layer_output(), then layer_output up the tree
+    static Rep3ToggledBatchedGrandProduct construct(WorkerEnv& env, ToggleH toggle) {
+        Rep3ToggledBatchedGrandProduct gp;
+        cozk_layer* l0 = nullptr;
+        rc_check(cozk_toggle_layer_output(env.ctx, toggle.h, env.party, &l0), env.ctx, "toggle_layer_output");
+        size_t batch = cozk_toggle_batch(toggle.h);
+        gp.sparse_layers = Rep3BatchedDenseGrandProduct::construct(env, LayerH(l0), batch);
+        gp.toggle_layer = std::move(toggle);
+        return gp;
+    }
+    size_t num_layers() const { return sparse_layers.layers.size() + 1; }
+
+    // prove_layer of the toggle layer (:850-873) with prove_sumcheck (sumcheck.rs:96-131) over cozk_toggle_round
+    static void prove_toggle_layer(WorkerEnv& env, cozk_toggle* t, const fe& claim_in, std::vector<fe>& r_grand_product) {
+        EqH eq;
+        std::vector<uint64_t> w = to_abi(r_grand_product);
+        int num_rounds = (int)r_grand_product.size();
+        rc_check(cozk_spliteq_new(env.ctx, w.data(), num_rounds, &eq.h), env.ctx, "spliteq_new");
+        if (env.party == 0) {
+            Writer wr;
+            wr.u64((uint64_t)num_rounds);
+            env.star->send_response(wr.b);
+        }
+        fe previous_claim = claim_in;
+        std::vector<fe> rs;
+        uint64_t rr[4];
+        for (int round = 0; round < num_rounds; round++) {
+            uint64_t ev[12];
+            rc_check(cozk_toggle_round(env.ctx, t, eq.h, round ? rr : nullptr, env.party, ev), env.ctx, "toggle_round");
+            fe g0 = fe_from_u64x4(ev);
+            fe pts[4] = {g0, Fr::sub(previous_claim, g0), fe_from_u64x4(ev + 4), fe_from_u64x4(ev + 8)};
+            std::vector<fe> cf(4);
+            unipoly_from_evals(pts, 4, cf.data());
+            Writer wr;
+            wr.vec_fr(cf);
+            env.star->send_response(wr.b);
+            Bytes req = env.star->receive_request();
+            Reader rd(req);
+            fe r_j = rd.fr();
+            previous_claim = env.additive_trivial(rd.fr());
+            rs.push_back(r_j);
+            fe_to_u64x4(r_j, rr);
+        }
+        if (num_rounds > 0) rc_check(cozk_toggle_bind(env.ctx, t, rr), env.ctx, "toggle_bind");
+        // final_claims (:825-835): (promote_to_trivial_share(flag), fingerprint)
+        uint64_t fl[4], pa[4], pb[4];
+        rc_check(cozk_toggle_final_claims(env.ctx, t, fl, pa, pb), env.ctx, "toggle_final_claims");
+        Share flag = env.rep3_trivial(fe_from_u64x4(fl));
+        Writer wr;
+        wr.fr(flag.a);
+        wr.fr(flag.b);
+        wr.fr(fe_from_u64x4(pa));
+        wr.fr(fe_from_u64x4(pb));
+        env.star->send_response(wr.b);
+        r_grand_product.assign(rs.rbegin(), rs.rend());
+    }
+
+    // prove_grand_product_worker (grand_product.rs:111-130) over layers() = [toggle, sparse...].rev() (:947-960)
+    std::vector<fe> prove_grand_product_worker(WorkerEnv& env) {
+        std::vector<fe> outputs = sparse_layers.claimed_outputs(env);
+        Writer w;
+        w.vec_fr(outputs);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        std::vector<fe> r = rd.vec_fr();
+        fe claim = env.additive_trivial(rd.fr());
+        for (size_t i = sparse_layers.layers.size(); i-- > 0;) Rep3BatchedDenseGrandProduct::prove_layer(env, sparse_layers.layers[i].h, claim, r);
+        prove_toggle_layer(env, toggle_layer.h, claim, r);
+        return r;
+    }
+};
+
+// coordinate_prove_layer of the toggle layer (sparse_grand_product.rs:876-903): no r_layer challenge, no claim fold
+static GrandProductLayerProof coordinate_prove_toggle_layer(StarNetCoordinator& net, Transcript& tr, std::vector<fe>& r_grand_product) {
+    GrandProductLayerProof lp;
+    Bytes nb = net.receive_response(0);
+    Reader rd(nb);
+    int num_rounds = (int)rd.u64();
+    std::vector<fe> r_sumcheck = coordinate_prove_arbitrary(net, tr, num_rounds, lp.proof);
+    receive_final_claims(net, lp.left_claim, lp.right_claim);
+    tr.append_scalar(lp.left_claim);
+    tr.append_scalar(lp.right_claim);
+    r_grand_product.assign(r_sumcheck.rbegin(), r_sumcheck.rend());
+    return lp;
+}
+
+// cooridinate_prove_grand_product (grand_product.rs:56-85) for the toggled circuit: num_layers - 1 multiplication layers,
+// then the toggle layer.  flag_claim / fingerprint_claim = the toggle layer's final claims at r_out.
+static GrandProductProof coordinate_prove_toggled_grand_product(StarNetCoordinator& net, Transcript& tr, size_t num_layers, std::vector<fe>& r_out) {
+    GrandProductProof proof;
+    std::vector<std::vector<fe>> parts;
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        parts.push_back(rd.vec_fr());
+    }
+    proof.outputs = combine_additive(parts);
+    tr.append_scalars(proof.outputs);
+    std::vector<fe> padded = proof.outputs;
+    while (padded.size() & (padded.size() - 1)) padded.push_back(Fr::zero());
+    int nv = 0;
+    while (((size_t)1 << nv) < padded.size()) nv++;
+    std::vector<fe> r = tr.challenge_vector(nv);
+    std::vector<fe> eq = eq_evals_host(r);
+    fe claim = Fr::zero();
+    for (size_t i = 0; i < padded.size(); i++) claim = Fr::add(claim, Fr::mul(eq[i], padded[i]));
+    Writer w;
+    w.vec_fr(r);
+    w.fr(claim);
+    net.broadcast_request(w.b);
+    for (size_t i = 0; i + 1 < num_layers; i++) proof.gkr_layers.push_back(coordinate_prove_layer(net, tr, claim, r));
+    proof.gkr_layers.push_back(coordinate_prove_toggle_layer(net, tr, r));
+    r_out = r;
+    return proof;
+}
+
+// plain verifier (jolt-core ToggledBatchedGrandProduct::verify_sumcheck_claim, out of tree): multiplication layers check
+// eq * L * R and fold with r_layer, the toggle layer (last) checks eq * (flag * fingerprint + 1 - flag)
+static bool verify_toggled_grand_product(const GrandProductProof& proof, Transcript& tr, fe& flag_claim, fe& fingerprint_claim, std::vector<fe>& r_out) {
+    tr.append_scalars(proof.outputs);
+    std::vector<fe> padded = proof.outputs;
+    while (padded.size() & (padded.size() - 1)) padded.push_back(Fr::zero());
+    int nv = 0;
+    while (((size_t)1 << nv) < padded.size()) nv++;
+    std::vector<fe> r = tr.challenge_vector(nv);
+    std::vector<fe> eqv = eq_evals_host(r);
+    fe claim = Fr::zero();
+    for (size_t i = 0; i < padded.size(); i++) claim = Fr::add(claim, Fr::mul(eqv[i], padded[i]));
+    fe one = Fr::one();
+    if (proof.gkr_layers.empty()) return false;
+    for (size_t li = 0; li < proof.gkr_layers.size(); li++) {
+        const GrandProductLayerProof& lp = proof.gkr_layers[li];
+        std::vector<fe> rs;
+        fe e = claim;
+        for (const auto& comp : lp.proof.compressed_polys) {
+            std::vector<fe> poly = unipoly_decompress(comp, e);
+            tr.append_scalars(comp);
+            fe r_j = tr.challenge_scalar();
+            rs.push_back(r_j);
+            e = unipoly_eval(poly, r_j);
+        }
+        if (rs.size() != r.size()) return false;
+        fe eq = one;
+        for (size_t i = 0; i < r.size(); i++) {
+            const fe& a = r[i];
+            const fe& b = rs[rs.size() - 1 - i];
+            eq = Fr::mul(eq, Fr::add(Fr::sub(Fr::sub(one, a), b), Fr::dbl(Fr::mul(a, b))));
+        }
+        tr.append_scalar(lp.left_claim);
+        tr.append_scalar(lp.right_claim);
+        r.assign(rs.rbegin(), rs.rend());
+        if (li + 1 < proof.gkr_layers.size()) {
+            if (!Fr::eq(Fr::mul(Fr::mul(eq, lp.left_claim), lp.right_claim), e)) return false;
+            fe r_layer = tr.challenge_scalar();
+            claim = Fr::add(lp.left_claim, Fr::mul(r_layer, Fr::sub(lp.right_claim, lp.left_claim)));
+            r.push_back(r_layer);
+        } else {
+            fe node = Fr::add(Fr::mul(lp.left_claim, lp.right_claim), Fr::sub(one, lp.left_claim));
+            if (!Fr::eq(Fr::mul(eq, node), e)) return false;
+            flag_claim = lp.left_claim;
+            fingerprint_claim = lp.right_claim;
+        }
+    }
+    r_out = r;
+    return true;
+}
+
 // ================================================================= PST13
 struct PST13Commitment {
     uint64_t nv;

@@ -2279,3 +2279,5 @@ int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out
 }
 
 }  // extern "C"
+
+#include "toggle_layer.inc"

@@ -290,6 +290,36 @@ int cozk_rep3_mul_vec_local(cozk_ctx* ctx, int mode, const cozk_vec* xa, const c
 /* claimed_outputs (grand_product.rs:266-272): out = (len/2) x 4 u64 additive products */
 int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out);
 
+/* ---- toggled / sparse batched grand product (co-jolt/src/subprotocols/sparse_grand_product.rs; Lasso's read / write
+ * memory checking of the instruction lookups, jolt/vm/instruction_lookups/worker.rs:763-859).
+ * cozk_toggle = Rep3BatchedGrandProductToggleLayer (sparse_grand_product.rs:30-70): public 0/1 flags (one U8 column of N
+ * entries per PAIR of circuits -- `flag_indices[batch_index / 2]`, :84) and shared fingerprints (2 * n_pairs circuits x N,
+ * circuit-major).  The Rep3SparseInterleavedPolynomial layers above it (co-jolt/src/poly/sparse_interleaved_poly.rs) are
+ * kept DENSE on the device -- a missing entry is a stored share of one -- i.e. they are ordinary cozk_layer objects:
+ * cozk_toggle_layer_output gives the first of them, cozk_layer_output_local + the ring reshare the rest, and
+ * cozk_layer_prove_rounds proves them; every party's round messages equal the reference's sparse computation. */
+typedef struct cozk_toggle cozk_toggle;
+/* Rep3BatchedGrandProductToggleLayer::new (:57-70); take_ownership != 0 adopts the fingerprint buffers */
+int cozk_toggle_create(cozk_ctx* ctx, int mode, const cozk_vec* const* flags, size_t n_pairs, cozk_vec* fp_a,
+                       cozk_vec* fp_b, int take_ownership, cozk_toggle** out);
+int cozk_toggle_free(cozk_toggle* t);
+size_t cozk_toggle_batch(const cozk_toggle* t); /* circuits = 2 * n_pairs */
+size_t cozk_toggle_len(const cozk_toggle* t);   /* fingerprints per circuit */
+/* layer_output (:76-97): entry b * N + i = flag ? fingerprint : promote_to_trivial_share(party_id, one) */
+int cozk_toggle_layer_output(cozk_ctx* ctx, const cozk_toggle* t, int party_id, cozk_layer** out);
+/* Rep3Bindable::bind (:153-290), incl. the coalesce step (:104-134) when one entry per circuit is left */
+int cozk_toggle_bind(cozk_ctx* ctx, cozk_toggle* t, const uint64_t r[4]);
+/* one round of prove_sumcheck over the toggle layer (compute_cubic, :311-823): bind layer + split-eq tables with the
+ * previous challenge r (NULL in the first round), then this party's additive g(0), g(2), g(3) of
+ * sum_x eq(x) (flag(x) fingerprint(x) + 1 - flag(x)) */
+int cozk_toggle_round(cozk_ctx* ctx, cozk_toggle* t, cozk_spliteq* eq, const uint64_t* r, int party_id,
+                      uint64_t out_evals[12]);
+/* final_claims (:825-835): the bound flag (public) and the bound fingerprint share */
+int cozk_toggle_final_claims(cozk_ctx* ctx, const cozk_toggle* t, uint64_t flag[4], uint64_t fp_a[4], uint64_t fp_b[4]);
+/* current (bound) flags and fingerprints -> host; any output pointer may be NULL */
+int cozk_toggle_download(cozk_ctx* ctx, const cozk_toggle* t, uint64_t* flags, uint64_t* fp_a, uint64_t* fp_b,
+                         size_t* n_flags, size_t* n_fp);
+
 /* SplitEqPolynomial::{new, bind} */
 int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out);
 int cozk_spliteq_free(cozk_spliteq* e);
@@ -487,6 +517,33 @@ const char* cozk_spartan_error(const cozk_spartan* h);
 int cozk_spartan_destroy(cozk_spartan* h);
 int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res);
 int cozk_spartan_proof_bytes(const cozk_spartan* h, uint8_t* out, size_t cap);
+
+/* ---------------------------------------------------------------- instruction-lookups harness ---- */
+/* SURVEY.md 8(f)1 restated synthetically: the toggled / sparse batched grand product of Lasso's read / write memory
+ * checking (jolt/vm/instruction_lookups/worker.rs:763-859 + subprotocols/sparse_grand_product.rs): n_pairs memories, each
+ * with one public 0/1 flag column over the 2^log_n cycles (density_pct % set) shared by its read and write circuit, and a
+ * shared fingerprint vector per circuit.  Workers on the GPU(s), coordinator + plain verifier on the calling thread. */
+typedef struct cozk_lookups cozk_lookups;
+typedef struct cozk_lookups_config {
+    int mode;        /* COZK_MODE_PLAIN / COZK_MODE_REP3 */
+    int log_n;       /* cycles N = 2^log_n */
+    int n_pairs;     /* memories: 2 * n_pairs circuits */
+    int density_pct; /* share of the flags that are set, 0..100 */
+    int devices[3];
+    uint64_t seed;
+} cozk_lookups_config;
+typedef struct cozk_lookups_result {
+    int verified; /* 1 ok, 0 rejected, -1 not run */
+    double wall_ms, t_construct_ms, t_prove_ms, t_worker_ms;
+    uint64_t bytes_star_up, bytes_star_down, bytes_ring, star_messages;
+    uint64_t proof_len;
+    uint8_t proof_digest[32];
+} cozk_lookups_result;
+int cozk_lookups_create(const cozk_lookups_config* cfg, cozk_lookups** out);
+const char* cozk_lookups_error(const cozk_lookups* h);
+int cozk_lookups_destroy(cozk_lookups* h);
+int cozk_lookups_prove(cozk_lookups* h, int verify, cozk_lookups_result* res);
+int cozk_lookups_proof_bytes(const cozk_lookups* h, uint8_t* out, size_t cap);
 
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation, k_msm_accum0) on the ctx stream,

@@ -1,0 +1,136 @@
+"""CPU tests (no GPU) of the toggled / sparse grand-product oracle (oracle/pysparse.py): the literal
+restatement of the reference's SPARSE algorithms (sparse_interleaved_poly.rs, sparse_grand_product.rs) must
+  * verify and open to the right products, with final claims equal to direct evaluations of the leaf polynomials;
+  * give the same proof for the plain prover and the 3-party Rep3 run (shares cancel in the coordinator's sums);
+  * agree, party by party and round by round, with the DENSE formulation the engine uses (missing entries stored as
+    shares of one; flags and fingerprints as dense vectors) -- the property the device kernels rely on."""
+import pytest
+
+import pylookups
+import pyref as O
+import pysparse as S
+
+R = O.R
+
+
+def _instance(batch, n, density, seed, nparties):
+    rng = O.SplitMix64(seed)
+    flags = [sorted(i for i in range(n) if rng.next() % 100 < density) for _ in range(batch // 2)]
+    vals = [[rng.field() for _ in range(n)] for _ in range(batch)]
+    if nparties == 1:
+        fps = [vals]
+    else:
+        sh = [[O.rep3_share(v, rng) for v in row] for row in vals]
+        fps = [[[s[p] for s in row] for row in sh] for p in range(3)]
+    return flags, vals, fps
+
+
+@pytest.mark.parametrize("batch,n,density", [(2, 8, 50), (4, 16, 30), (6, 8, 60), (2, 4, 100), (4, 8, 0), (6, 32, 10), (10, 16, 25)])
+def test_toggled_grand_product_verifies_and_plain_equals_rep3(batch, n, density):
+    proofs = []
+    for nparties in (1, 3):
+        flags, vals, fps = _instance(batch, n, density, 7, nparties)
+        toggles, sparse = S.toggled_construct(flags, fps)
+        proof, r = S.toggled_prove(toggles, sparse, O.Transcript(b"t"))
+        v = S.toggled_verify(proof, O.Transcript(b"t"))
+        assert v is not None and v[2] == r
+        assert (v[0], v[1]) == S.toggled_leaf_mles(flags, vals, r)
+        for b in range(batch):
+            s, p = set(flags[b // 2]), 1
+            for i in s:
+                p = p * vals[b][i] % R
+            assert proof["outputs"][b] == p
+        proofs.append(proof)
+    assert proofs[0] == proofs[1]
+
+
+def _toggle_dense_evals(flags_dense, fps_dense, half_n, eq, party, nparties):
+    """the engine's formulation of the toggle layer's round sums (csrc/toggle_layer.inc k_toggle_cubic): dense flags and
+    fingerprints, pair j of circuit b uses the flag pair of circuit b >> 1 (half_n = pairs per circuit; 0: coalesced)"""
+    npairs = len(fps_dense) // 2
+    s = [0, 0, 0]
+    nested = eq.E1_len != 1
+    E1h = eq.E1_len // 2
+    limit = E1h * eq.E2_len if nested else eq.E2_len // 2
+    for j in range(min(npairs, limit)):
+        if nested:
+            x2, x1 = divmod(j, E1h)
+            e = [v * eq.E2[x2] % R for v in S._eq3(eq.E1[2 * x1], eq.E1[2 * x1 + 1])]
+        else:
+            e = S._eq3(eq.E2[2 * j], eq.E2[2 * j + 1])
+        fj = j
+        if half_n:
+            b, i = divmod(j, half_n)
+            fj = (b >> 1) * half_n + i
+        f = S._eq3(flags_dense[2 * fj], flags_dense[2 * fj + 1])
+        p0, p1 = O.sh_into_additive(fps_dense[2 * j]), O.sh_into_additive(fps_dense[2 * j + 1])
+        p = S._eq3(p0, p1)
+        for k in range(3):
+            s[k] = (s[k] + e[k] * (p[k] * f[k] + ((1 - f[k]) if party == 0 else 0))) % R
+    return s
+
+
+@pytest.mark.parametrize("batch,n,density,nparties", [(4, 16, 30, 3), (6, 8, 60, 3), (6, 8, 60, 1), (2, 32, 15, 3), (10, 4, 50, 1)])
+def test_sparse_algorithms_equal_the_dense_formulation_party_by_party(batch, n, density, nparties):
+    flags, vals, fps = _instance(batch, n, density, 11, nparties)
+    toggles, sparse = S.toggled_construct(flags, fps)
+    rng = O.SplitMix64(99)
+    # ---- a sparse layer: compute_cubic == dense compute_cubic of coalesce(), bind == dense bind, every round
+    for layer_set in (sparse[0], sparse[1] if len(sparse) > 1 else sparse[0]):
+        nv = max(1, (layer_set[0].dense_len // 2 - 1).bit_length())
+        w = [rng.field() for _ in range(nv)]
+        for p in range(nparties):
+            import copy
+            lay = copy.deepcopy(layer_set[p])
+            dense = lay.coalesce()
+            eq_s, eq_d = O.SplitEq(w), O.SplitEq(w)
+            claim = rng.field()
+            for _ in range(nv):
+                assert lay.compute_cubic_evals(eq_s, claim) == O.interleaved_compute_cubic_evals(dense, eq_d, claim)
+                r = rng.field()
+                lay.bind(r)
+                dense = O.interleaved_bind(dense, r)
+                eq_s.bind(r)
+                eq_d.bind(r)
+                assert lay.coalesce() == dense
+    # ---- the toggle layer: the four cases == the dense sums over (flags, fingerprints)
+    L = 1 << (batch - 1).bit_length()
+    nv = (L * n).bit_length() - 1
+    w = [rng.field() for _ in range(nv)]
+    for p in range(nparties):
+        import copy
+        t = copy.deepcopy(toggles[p])
+        fl_dense = [1 if i in set(flags[q]) else 0 for q in range(batch // 2) for i in range(n)]
+        fp_dense = [v for row in fps[p] for v in row]
+        half_n, coalesced = n // 2, False
+        eq_s, eq_d = O.SplitEq(w), O.SplitEq(w)
+        claim = rng.field()
+        for _ in range(nv):
+            ev = t.compute_cubic_evals(eq_s, claim)
+            ds = _toggle_dense_evals(fl_dense, fp_dense, 0 if coalesced else half_n, eq_d, p, nparties)
+            assert [ev[0], ev[2], ev[3]] == ds
+            r = rng.field()
+            t.bind(r)
+            eq_s.bind(r)
+            eq_d.bind(r)
+            fl_dense = O.public_bind(fl_dense, r, O.LOW_TO_HIGH)
+            fp_dense = O.dense_bind(fp_dense, r, O.LOW_TO_HIGH)
+            if not coalesced:
+                half_n //= 2
+                if half_n == 0:  # one entry per circuit left: coalesce (sparse_grand_product.rs:104-134)
+                    zero = S.zero_share(nparties)
+                    fl_dense = [fl_dense[c >> 1] if c < batch else 1 for c in range(L)]
+                    fp_dense = [fp_dense[c] if c < batch else zero for c in range(L)]
+                    coalesced = True
+        fl, fp = t.final_claims()
+        assert fp == fp_dense[0]
+        assert (fl if nparties == 1 else O.rep3_open([O.rep3_promote_from_trivial(fl_dense[0], q) for q in range(3)])) == fl_dense[0]
+
+
+def test_pipeline_oracle_small():
+    for mode in ("plain", "rep3"):
+        out = pylookups.run(dict(mode=mode, log_n=3, n_pairs=2, density_pct=40, seed=5))
+        assert out["verified"]
+    a = pylookups.run(dict(mode="plain", log_n=3, n_pairs=3, density_pct=30, seed=9))
+    b = pylookups.run(dict(mode="rep3", log_n=3, n_pairs=3, density_pct=30, seed=9))
+    assert a["verified"] and a["digest"] == b["digest"]
