@@ -17,7 +17,11 @@ struct LookupsParty {
     int party = 0;
     std::vector<VecH> flags;  // n_pairs U8 columns
     VecH fp_a, fp_b;          // 2 * n_pairs circuits x N, circuit-major
-    double t_construct = 0, t_prove = 0, t_total = 0;
+    // primary sumcheck (cfg.primary): instruction flags, E polynomials, lookup_outputs
+    std::vector<VecH> instr_flags;
+    std::vector<PolyH> E;
+    PolyH outputs;
+    double t_primary = 0, t_construct = 0, t_prove = 0, t_total = 0;
     uint64_t star_up = 0, star_down = 0, star_msgs = 0, ring_bytes = 0;
     std::string error;
 };
@@ -30,6 +34,11 @@ struct cozk_lookups {
     // the verifier's own view: plain flags (as Fr polynomials) and plain fingerprints, on its own context
     cozk_ctx* vctx = nullptr;
     std::vector<PolyH> v_flags, v_fps;
+    std::vector<cozk_primary_instr> instrs;
+    std::vector<uint8_t> which;            // instruction of every cycle
+    std::vector<fe> outputs_plain;         // lookup_outputs in the clear (the dealer's view)
+    std::vector<PolyH> v_E, v_iflags;
+    PolyH v_outputs;
     std::string error;
     Bytes last_proof;
 };
@@ -41,6 +50,95 @@ std::vector<uint8_t> lookups_flag_column(const cozk_lookups_config& c, int q, si
     const uint64_t seed = c.seed + 4000ull * (uint64_t)(q + 1);
     for (size_t i = 0; i < n; i++) col[i] = (uint32_t)synthetic_small_host(seed, i, 8) * 100u < (uint32_t)c.density_pct * 256u ? 1 : 0;
     return col;
+}
+
+// the synthetic instruction table of the primary sumcheck: three CONCAT (AND / OR / XOR-like), one PRODUCT (BEQ-like) and
+// one LTU (SLTU-like) instruction with C = 4 chunks over memory indices taken modulo n_mem
+std::vector<cozk_primary_instr> lookups_instr_table(int n_mem) {
+    auto mk = [&](int form, std::initializer_list<int> mems, int bits) {
+        cozk_primary_instr in{};
+        in.form = form;
+        in.bits = bits;
+        in.n_mems = 0;
+        for (int m : mems) in.mems[in.n_mems++] = m % n_mem;
+        return in;
+    };
+    return {mk(COZK_G_CONCAT, {0, 1, 2, 3}, 8), mk(COZK_G_CONCAT, {4, 5, 6, 7}, 8), mk(COZK_G_CONCAT, {4, 1, 6, 3}, 4), mk(COZK_G_PRODUCT, {8, 9, 10, 11}, 0),
+            mk(COZK_G_LTU, {12, 13, 14, 15, 16, 17, 18}, 0)};
+}
+
+// the dealer's view: which instruction every cycle runs and lookup_outputs(x) = g_{which(x)}(E(x)) in the clear
+void lookups_setup_primary_clear(cozk_lookups* h) {
+    const cozk_lookups_config& c = h->cfg;
+    h->instrs = lookups_instr_table(c.n_pairs);
+    h->which.resize(h->N);
+    h->outputs_plain.resize(h->N);
+    std::vector<fe> E((size_t)c.n_pairs);
+    for (size_t x = 0; x < h->N; x++) {
+        uint8_t w = (uint8_t)(synthetic_small_host(c.seed + 1234567ull, x, 8) % h->instrs.size());
+        h->which[x] = w;
+        const cozk_primary_instr& in = h->instrs[w];
+        for (int t = 0; t < in.n_mems; t++) E[in.mems[t]] = synthetic_fr_host(c.seed + 9000ull * (uint64_t)(in.mems[t] + 1), x);
+        h->outputs_plain[x] = primary_g_plain(in, E);
+    }
+}
+
+void lookups_setup_primary_party(cozk_lookups* h, LookupsParty& ps) {
+    const cozk_lookups_config& c = h->cfg;
+    cozk_ctx* ctx = ps.ctx;
+    for (size_t i = 0; i < h->instrs.size(); i++) {
+        std::vector<uint8_t> col(h->N);
+        for (size_t x = 0; x < h->N; x++) col[x] = h->which[x] == i ? 1 : 0;
+        cozk_vec* v = nullptr;
+        rc_check(cozk_vec_upload(ctx, col.data(), h->N, COZK_SCALAR_U8, &v), ctx, "vec_upload(instruction flags)");
+        ps.instr_flags.push_back(VecH(v));
+    }
+    for (int m = 0; m < c.n_pairs; m++) {
+        VecH a, b;
+        make_share_vectors(ctx, h->N, c.seed + 9000ull * (uint64_t)(m + 1), ps.party, c.mode, a, b);
+        cozk_poly* p = nullptr;
+        rc_check(cozk_poly_create(ctx, c.mode, a.h, b.h, &p), ctx, "poly_create(E)");
+        ps.E.push_back(PolyH(p));
+    }
+    cozk_vec* ov = nullptr;
+    rc_check(cozk_vec_upload(ctx, h->outputs_plain.data(), h->N, COZK_SCALAR_FR, &ov), ctx, "vec_upload(outputs)");
+    VecH ovh(ov);
+    cozk_poly* op = nullptr;
+    if (c.mode == COZK_MODE_REP3) {
+        uint8_t k0[COZK_PRF_KEY_BYTES], k1[COZK_PRF_KEY_BYTES];
+        harness_prf_key(c.seed + 555ull, 101, k0);
+        harness_prf_key(c.seed + 555ull, 102, k1);
+        cozk_vec *sa = nullptr, *sb = nullptr;
+        rc_check(cozk_rep3_share_vec(ctx, ovh.h, k0, k1, 0, ps.party, &sa, &sb), ctx, "rep3_share_vec(outputs)");
+        VecH a(sa), b(sb);
+        rc_check(cozk_poly_create(ctx, COZK_MODE_REP3, a.h, b.h, &op), ctx, "poly_create(outputs)");
+    } else {
+        rc_check(cozk_poly_create(ctx, COZK_MODE_PLAIN, ovh.h, nullptr, &op), ctx, "poly_create(outputs)");
+    }
+    ps.outputs = PolyH(op);
+}
+
+void lookups_setup_primary_verifier(cozk_lookups* h) {
+    const cozk_lookups_config& c = h->cfg;
+    cozk_ctx* ctx = h->vctx;
+    auto plain_poly = [&](const VecH& v) {
+        cozk_poly* p = nullptr;
+        rc_check(cozk_poly_create(ctx, COZK_MODE_PLAIN, v.h, nullptr, &p), ctx, "poly_create");
+        return PolyH(p);
+    };
+    for (int m = 0; m < c.n_pairs; m++) h->v_E.push_back(plain_poly(make_vec_random(ctx, h->N, COZK_SCALAR_FR, c.seed + 9000ull * (uint64_t)(m + 1), 0)));
+    for (size_t i = 0; i < h->instrs.size(); i++) {
+        std::vector<fe> f(h->N);
+        for (size_t x = 0; x < h->N; x++) f[x] = h->which[x] == i ? Fr::one() : Fr::zero();
+        cozk_vec* v = nullptr;
+        rc_check(cozk_vec_upload(ctx, f.data(), h->N, COZK_SCALAR_FR, &v), ctx, "vec_upload");
+        VecH vh(v);
+        h->v_iflags.push_back(plain_poly(vh));
+    }
+    cozk_vec* ov = nullptr;
+    rc_check(cozk_vec_upload(ctx, h->outputs_plain.data(), h->N, COZK_SCALAR_FR, &ov), ctx, "vec_upload");
+    VecH ovh(ov);
+    h->v_outputs = plain_poly(ovh);
 }
 
 void lookups_setup_party(cozk_lookups* h, LookupsParty& ps) {
@@ -93,9 +191,16 @@ void lookups_setup_verifier(cozk_lookups* h) {
 }
 
 struct LookupsProof {
+    bool has_primary = false;
+    PrimarySumcheckProof primary;
     GrandProductProof gp;
     Bytes serialize() const {
         Writer w;
+        if (has_primary) {
+            w.u64(primary.compressed_polys.size());
+            for (auto& p : primary.compressed_polys) w.vec_fr(p);
+            w.vec_fr(primary.openings);
+        }
         w.vec_fr(gp.outputs);
         w.u64(gp.gkr_layers.size());
         for (auto& l : gp.gkr_layers) {
@@ -119,7 +224,29 @@ void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star,
     harness_prf_key(c.seed, (uint64_t)ps.party, env.key_self);
     harness_prf_key(c.seed, (uint64_t)((ps.party + 2) % 3), env.key_prev);
     HIP_TRY(hipSetDevice(ps.ctx->device));
+    double tp0 = now_ms();
+    if (c.primary) {
+        // ---- Lasso primary sumcheck (jolt/vm/instruction_lookups/worker.rs:95-141): r_eq from the coordinator, eq table,
+        //      then prove_primary_sumcheck_inner
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        std::vector<fe> r_eq = rd.vec_fr();
+        std::vector<uint64_t> w = to_abi(r_eq);
+        cozk_vec* eqv = nullptr;
+        rc_check(cozk_eq_evals(env.ctx, w.data(), (int)r_eq.size(), &eqv), env.ctx, "eq_evals");
+        VecH eqh(eqv);
+        std::vector<const cozk_vec*> fl;
+        for (auto& f : ps.instr_flags) fl.push_back(f.h);
+        std::vector<const cozk_poly*> E;
+        for (auto& e : ps.E) E.push_back(e.h);
+        cozk_primary* pr = nullptr;
+        rc_check(cozk_primary_create(env.ctx, c.mode, ps.party, h->instrs.data(), h->instrs.size(), fl.data(), E.data(), E.size(), ps.outputs.h, eqh.h, &pr),
+                 env.ctx, "primary_create");
+        PrimaryH prh(pr);
+        (void)prove_primary_sumcheck_worker(env, pr, c.log_n, E.size(), h->instrs.size());
+    }
     double t0 = now_ms();
+    ps.t_primary = t0 - tp0;
     // the leaves are consumed by the prover: work on copies of the resident fingerprints
     cozk_vec *fa = nullptr, *fb = nullptr;
     size_t total = h->batch * h->N;
@@ -142,7 +269,7 @@ void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star,
     (void)gp.prove_grand_product_worker(env);
     double t2 = now_ms();
     ps.t_prove = t2 - t1;
-    ps.t_total = t2 - t0;
+    ps.t_total = t2 - tp0;
     ps.star_up = star->bytes_up;
     ps.star_down = star->bytes_down;
     ps.star_msgs = star->n_msgs;
@@ -174,11 +301,46 @@ fe lookups_eval_circuit_major(cozk_lookups* h, const std::vector<const cozk_poly
 
 int lookups_coordinator_main(cozk_lookups* h, StarNetCoordinator& net, LookupsProof& proof, bool verify, std::string& why) {
     Transcript tr("cozk-lookups");
+    std::vector<fe> r_eq, r_primary;
+    if (h->cfg.primary) {
+        r_eq = tr.challenge_vector((size_t)h->cfg.log_n);
+        Writer w;
+        w.vec_fr(r_eq);
+        net.broadcast_request(w.b);
+        proof.has_primary = true;
+        proof.primary = coordinate_primary_sumcheck(net, tr, h->cfg.log_n, r_primary);
+    }
     size_t num_layers = (size_t)h->cfg.log_n + 1;  // tree_depth sparse layers + the toggle layer
     std::vector<fe> r;
     proof.gp = coordinate_prove_toggled_grand_product(net, tr, num_layers, r);
     if (!verify) return -1;
     Transcript vt("cozk-lookups");
+    if (h->cfg.primary) {
+        std::vector<fe> vr_eq = vt.challenge_vector((size_t)h->cfg.log_n), rs;
+        const int degree = 6;  // max g degree (C = 4) + 2
+        if (!verify_primary_sumcheck(proof.primary, h->instrs, (size_t)h->cfg.n_pairs, degree, vr_eq, vt, rs)) {
+            why = "primary sumcheck: a round or the final claim does not hold";
+            return 0;
+        }
+        // the opened evaluations against direct evaluations of the polynomials (stand-in for the PCS opening)
+        std::vector<fe> pt(rs.rbegin(), rs.rend());
+        std::vector<uint64_t> w = to_abi(pt);
+        HIP_TRY(hipSetDevice(h->vctx->device));
+        cozk_vec* chi = nullptr;
+        rc_check(cozk_eq_evals(h->vctx, w.data(), (int)pt.size(), &chi), h->vctx, "eq_evals");
+        VecH chih(chi);
+        std::vector<const cozk_poly*> ps;
+        for (auto& e : h->v_E) ps.push_back(e.h);
+        for (auto& f : h->v_iflags) ps.push_back(f.h);
+        ps.push_back(h->v_outputs.h);
+        std::vector<uint64_t> out(4 * ps.size());
+        rc_check(cozk_poly_batch_evaluate_at_chi(h->vctx, ps.data(), ps.size(), chih.h, out.data()), h->vctx, "batch_evaluate");
+        for (size_t i = 0; i < ps.size(); i++)
+            if (!Fr::eq(fe_from_u64x4(out.data() + 4 * i), proof.primary.openings[i])) {
+                why = "primary sumcheck: opening " + std::to_string(i) + " != polynomial(r)";
+                return 0;
+            }
+    }
     fe flag_claim, fp_claim;
     std::vector<fe> rv;
     if (!verify_toggled_grand_product(proof.gp, vt, flag_claim, fp_claim, rv)) {
@@ -230,6 +392,7 @@ int cozk_lookups_create(const cozk_lookups_config* cfg, cozk_lookups** out) {
         h->N = (size_t)1 << cfg->log_n;
         h->batch = 2 * (size_t)cfg->n_pairs;
         h->parties.resize(h->nparties);
+        if (cfg->primary) lookups_setup_primary_clear(h);
         for (int p = 0; p < h->nparties; p++) {
             LookupsParty& ps = h->parties[p];
             ps.party = p;
@@ -239,11 +402,13 @@ int cozk_lookups_create(const cozk_lookups_config* cfg, cozk_lookups** out) {
             cozk_ctx_set_resident_rounds(ps.ctx, h->nparties > 1 ? 0 : 1);
             HIP_TRY(hipSetDevice(ps.ctx->device));
             lookups_setup_party(h, ps);
+            if (cfg->primary) lookups_setup_primary_party(h, ps);
         }
         int rc = cozk_ctx_create(cfg->devices[0], &h->vctx);
         if (rc != COZK_OK) throw CozkError(rc, "lookups: cannot create the verifier's context");
         HIP_TRY(hipSetDevice(h->vctx->device));
         lookups_setup_verifier(h);
+        if (cfg->primary) lookups_setup_primary_verifier(h);
     } catch (const CozkError& e) {
         h->error = e.what();
         *out = h;
@@ -266,12 +431,18 @@ int cozk_lookups_destroy(cozk_lookups* h) {
         ps.flags.clear();
         ps.fp_a = VecH();
         ps.fp_b = VecH();
+        ps.instr_flags.clear();
+        ps.E.clear();
+        ps.outputs = PolyH();
         if (ps.own_ctx && ps.ctx) cozk_ctx_destroy(ps.ctx);
     }
     if (h->vctx) {
         (void)hipSetDevice(h->vctx->device);
         h->v_flags.clear();
         h->v_fps.clear();
+        h->v_E.clear();
+        h->v_iflags.clear();
+        h->v_outputs = PolyH();
         cozk_ctx_destroy(h->vctx);
     }
     delete h;
@@ -330,6 +501,7 @@ int cozk_lookups_prove(cozk_lookups* h, int verify, cozk_lookups_result* res) {
     res->wall_ms = t1 - t0;
     for (int p = 0; p < np; p++) {
         LookupsParty& ps = h->parties[p];
+        res->t_primary_ms = std::max(res->t_primary_ms, ps.t_primary);
         res->t_construct_ms = std::max(res->t_construct_ms, ps.t_construct);
         res->t_prove_ms = std::max(res->t_prove_ms, ps.t_prove);
         res->t_worker_ms = std::max(res->t_worker_ms, ps.t_total);

@@ -641,6 +641,183 @@ static bool verify_toggled_grand_product(const GrandProductProof& proof, Transcr
     return true;
 }
 
+// ================================================================= Lasso primary sumcheck (instruction lookups)
+struct PrimaryH {
+    cozk_primary* h = nullptr;
+    PrimaryH() {}
+    explicit PrimaryH(cozk_primary* p) : h(p) {}
+    PrimaryH(const PrimaryH&) = delete;
+    PrimaryH& operator=(const PrimaryH&) = delete;
+    PrimaryH(PrimaryH&& o) noexcept : h(o.h) { o.h = nullptr; }
+    ~PrimaryH() { cozk_primary_free(h); }
+};
+
+// UniPoly::from_evals for any number of points 0, 1, .., n-1 (Lagrange with small-integer denominators)
+static inline std::vector<fe> unipoly_from_evals_general(const std::vector<fe>& ev) {
+    const size_t n = ev.size();
+    std::vector<fe> coeffs(n, Fr::zero());
+    for (size_t i = 0; i < n; i++) {
+        std::vector<fe> num(1, Fr::one());  // prod_{j != i} (x - j), low -> high
+        fe den = Fr::one();
+        for (size_t j = 0; j < n; j++) {
+            if (j == i) continue;
+            std::vector<fe> nx(num.size() + 1, Fr::zero());
+            fe jj = Fr::from_u64((uint64_t)j);
+            for (size_t k = 0; k < num.size(); k++) {
+                nx[k + 1] = Fr::add(nx[k + 1], num[k]);
+                nx[k] = Fr::sub(nx[k], Fr::mul(jj, num[k]));
+            }
+            num.swap(nx);
+            fe d = i > j ? Fr::from_u64((uint64_t)(i - j)) : Fr::neg(Fr::from_u64((uint64_t)(j - i)));
+            den = Fr::mul(den, d);
+        }
+        fe sc = Fr::mul(ev[i], Fr::inv(den));
+        for (size_t k = 0; k < n; k++) coeffs[k] = Fr::add(coeffs[k], Fr::mul(sc, num[k]));
+    }
+    return coeffs;
+}
+
+// prove_primary_sumcheck_inner (jolt/vm/instruction_lookups/worker.rs:375-452): per round the `degree` additive evaluations
+// go up, r_j comes down; every multiplication level of the collations is one mul_vec over all items (local half on the
+// device, ring reshare here).  Afterwards the final claims are sent as additive shares in the order E, flags, outputs
+// (the primary_sumcheck_openings of worker.rs:128-141).  Returns the challenges in round order.
+static std::vector<fe> prove_primary_sumcheck_worker(WorkerEnv& env, cozk_primary* prim, int num_rounds, size_t n_mem, size_t n_instr) {
+    const int D = cozk_primary_degree(prim);
+    std::vector<fe> rs;
+    uint64_t rr[4];
+    for (int round = 0; round < num_rounds; round++) {
+        size_t n_items = 0;
+        int n_levels = 0;
+        rc_check(cozk_primary_round_begin(env.ctx, prim, round ? rr : nullptr, &n_items, &n_levels), env.ctx, "primary_round_begin");
+        for (int level = 1; level <= n_levels; level++) {
+            const void* send = nullptr;
+            void* recv = nullptr;
+            size_t n = 0;
+            rc_check(cozk_primary_level(env.ctx, prim, level, env.key_self, env.key_prev, env.mask_ctr, &send, &recv, &n), env.ctx, "primary_level");
+            if (env.mode == COZK_MODE_REP3) {
+                env.ring->reshare(env.ctx, (const fe*)send, (fe*)recv, n);
+                env.mask_ctr += n;
+            }
+        }
+        std::vector<uint64_t> ev(4 * (size_t)D);
+        rc_check(cozk_primary_round_finish(env.ctx, prim, ev.data()), env.ctx, "primary_round_finish");
+        std::vector<fe> msg((size_t)D);
+        for (int k = 0; k < D; k++) msg[k] = fe_from_u64x4(ev.data() + 4 * k);
+        Writer w;
+        w.vec_fr(msg);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe r_j = rd.fr();
+        rs.push_back(r_j);
+        fe_to_u64x4(r_j, rr);
+    }
+    std::vector<uint64_t> Ee(8 * n_mem), Fe(4 * n_instr);
+    uint64_t oe[8], qe[4];
+    rc_check(cozk_primary_final_evals(env.ctx, prim, rr, Ee.data(), Fe.data(), oe, qe), env.ctx, "primary_final_evals");
+    std::vector<fe> openings;
+    for (size_t m = 0; m < n_mem; m++) openings.push_back(env.into_additive(Share{fe_from_u64x4(Ee.data() + 8 * m), fe_from_u64x4(Ee.data() + 8 * m + 4)}));
+    for (size_t i = 0; i < n_instr; i++) openings.push_back(env.mode == COZK_MODE_REP3 ? env.additive_trivial(fe_from_u64x4(Fe.data() + 4 * i)) : fe_from_u64x4(Fe.data() + 4 * i));
+    openings.push_back(env.into_additive(Share{fe_from_u64x4(oe), fe_from_u64x4(oe + 4)}));
+    Writer w;
+    w.vec_fr(openings);
+    env.star->send_response(w.b);
+    return rs;
+}
+
+struct PrimarySumcheckProof {
+    std::vector<std::vector<fe>> compressed_polys;
+    std::vector<fe> openings;  // E(r) (n_mem), flags(r) (n_instr), lookup_outputs(r)
+};
+
+// prove_primary_sumcheck_rep3 (jolt/vm/instruction_lookups/coordinator.rs:97-150) + the final claims
+static PrimarySumcheckProof coordinate_primary_sumcheck(StarNetCoordinator& net, Transcript& tr, int num_rounds, std::vector<fe>& r_out) {
+    PrimarySumcheckProof proof;
+    fe previous_claim = Fr::zero();
+    r_out.clear();
+    for (int round = 0; round < num_rounds; round++) {
+        std::vector<std::vector<fe>> parts;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            parts.push_back(rd.vec_fr());
+        }
+        std::vector<fe> ev = combine_additive(parts);
+        ev.insert(ev.begin() + 1, Fr::sub(previous_claim, ev[0]));  // round_evals.insert(1, previous_claim - round_evals[0])
+        std::vector<fe> poly = unipoly_from_evals_general(ev);
+        std::vector<fe> comp = unipoly_compress(poly);
+        tr.append_scalars(comp);
+        proof.compressed_polys.push_back(comp);
+        fe r_j = tr.challenge_scalar();
+        Writer w;
+        w.fr(r_j);
+        net.broadcast_request(w.b);
+        r_out.push_back(r_j);
+        previous_claim = unipoly_eval(poly, r_j);
+    }
+    std::vector<std::vector<fe>> parts;
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        parts.push_back(rd.vec_fr());
+    }
+    proof.openings = combine_additive(parts);
+    tr.append_scalars(proof.openings);
+    return proof;
+}
+
+// g_i on opened values (the verifier's side of combine_lookups)
+static inline fe primary_g_plain(const cozk_primary_instr& in, const std::vector<fe>& E) {
+    if (in.form == COZK_G_CONCAT) {
+        fe shift = Fr::one(), two = Fr::from_u64(2);
+        for (int b = 0; b < in.bits; b++) shift = Fr::mul(shift, two);
+        fe acc = Fr::zero(), w = Fr::one();
+        for (int t = in.n_mems - 1; t >= 0; t--) {
+            acc = Fr::add(acc, Fr::mul(E[in.mems[t]], w));
+            w = Fr::mul(w, shift);
+        }
+        return acc;
+    }
+    if (in.form == COZK_G_PRODUCT) {
+        fe acc = Fr::one();
+        for (int t = 0; t < in.n_mems; t++) acc = Fr::mul(acc, E[in.mems[t]]);
+        return acc;
+    }
+    int C = (in.n_mems + 1) / 2;
+    fe s = Fr::zero(), prod = Fr::one();
+    for (int i = 0; i < C; i++) {
+        s = Fr::add(s, Fr::mul(E[in.mems[i]], prod));
+        if (i < C - 1) prod = Fr::mul(prod, E[in.mems[C + i]]);
+    }
+    return s;
+}
+
+// plain verifier of the primary sumcheck (jolt-core verify_primary_sumcheck, out of tree): replay, then
+// claim == eq(r_eq, r) (sum_i flag_i(r) g_i(E(r)) - outputs(r)); the point is the reversed challenge list (LowToHigh)
+static bool verify_primary_sumcheck(const PrimarySumcheckProof& proof, const std::vector<cozk_primary_instr>& instrs, size_t n_mem, int degree,
+                                    const std::vector<fe>& r_eq, Transcript& tr, std::vector<fe>& r_out) {
+    fe claim = Fr::zero();
+    r_out.clear();
+    for (const auto& comp : proof.compressed_polys) {
+        if ((int)comp.size() != degree) return false;
+        std::vector<fe> poly = unipoly_decompress(comp, claim);
+        tr.append_scalars(comp);
+        fe r_j = tr.challenge_scalar();
+        r_out.push_back(r_j);
+        claim = unipoly_eval(poly, r_j);
+    }
+    if (proof.openings.size() != n_mem + instrs.size() + 1 || r_out.size() != r_eq.size()) return false;
+    tr.append_scalars(proof.openings);
+    std::vector<fe> E(proof.openings.begin(), proof.openings.begin() + n_mem);
+    fe one = Fr::one(), eq = one;
+    for (size_t i = 0; i < r_eq.size(); i++) {
+        const fe& a = r_eq[i];
+        const fe& b = r_out[r_out.size() - 1 - i];
+        eq = Fr::mul(eq, Fr::add(Fr::sub(Fr::sub(one, a), b), Fr::dbl(Fr::mul(a, b))));
+    }
+    fe acc = Fr::zero();
+    for (size_t i = 0; i < instrs.size(); i++) acc = Fr::add(acc, Fr::mul(proof.openings[n_mem + i], primary_g_plain(instrs[i], E)));
+    return Fr::eq(Fr::mul(eq, Fr::sub(acc, proof.openings.back())), claim);
+}
+
 // ================================================================= PST13
 struct PST13Commitment {
     uint64_t nv;

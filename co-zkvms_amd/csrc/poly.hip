@@ -2281,3 +2281,4 @@ int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out
 }  // extern "C"
 
 #include "toggle_layer.inc"
+#include "primary_sumcheck.inc"

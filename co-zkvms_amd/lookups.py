@@ -12,11 +12,12 @@ from .engine import Vec, fr_to_mont_limbs, mont_limbs_to_int
 
 class LookupsConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("n_pairs", ctypes.c_int), ("density_pct", ctypes.c_int),
-                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64)]
+                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64), ("primary", ctypes.c_int)]
 
 
 class LookupsResult(ctypes.Structure):
-    _fields_ = [("verified", ctypes.c_int), ("wall_ms", ctypes.c_double), ("t_construct_ms", ctypes.c_double), ("t_prove_ms", ctypes.c_double),
+    _fields_ = [("verified", ctypes.c_int), ("wall_ms", ctypes.c_double), ("t_primary_ms", ctypes.c_double), ("t_construct_ms", ctypes.c_double),
+                ("t_prove_ms", ctypes.c_double),
                 ("t_worker_ms", ctypes.c_double), ("bytes_star_up", ctypes.c_uint64), ("bytes_star_down", ctypes.c_uint64),
                 ("bytes_ring", ctypes.c_uint64), ("star_messages", ctypes.c_uint64), ("proof_len", ctypes.c_uint64),
                 ("proof_digest", ctypes.c_uint8 * 32)]
@@ -63,13 +64,14 @@ def _decl():
 
 
 class LookupsHarness:
-    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1):
+    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1, primary=False):
         self._l = _decl()
         cfg = LookupsConfig()
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
         cfg.log_n, cfg.n_pairs, cfg.density_pct = log_n, n_pairs, density_pct
         cfg.devices = (ctypes.c_int * 3)(*devices)
         cfg.seed = seed
+        cfg.primary = 1 if primary else 0
         h = _vp()
         rc = self._l.cozk_lookups_create(ctypes.byref(cfg), ctypes.byref(h))
         self.h = h

@@ -320,6 +320,48 @@ int cozk_toggle_final_claims(cozk_ctx* ctx, const cozk_toggle* t, uint64_t flag[
 int cozk_toggle_download(cozk_ctx* ctx, const cozk_toggle* t, uint64_t* flags, uint64_t* fp_a, uint64_t* fp_b,
                          size_t* n_flags, size_t* n_fp);
 
+/* ---- Lasso's primary sumcheck of the instruction lookups (co-jolt/src/jolt/vm/instruction_lookups/worker.rs:180-720):
+ *   sum_x eq(r, x) ( sum_i flag_i(x) g_i(E_1(x), .., E_alpha(x)) - lookup_output(x) ) = 0.
+ * cozk_primary holds eq (public), the instruction flags (public 0/1 U8 columns), the E polynomials and lookup_outputs
+ * (shared) and binds them LowToHigh once per round.  The collations g_i (combine_lookups_rep3_batched,
+ * co-jolt/src/jolt/instruction/*.rs) are given as a table of forms over memory indices:
+ *   COZK_G_CONCAT  (and.rs:89-101, utils/instruction_utils.rs:26-47): sum_j 2^(bits (n-1-j)) E_mems[j]        -- local
+ *   COZK_G_PRODUCT (beq.rs:106-130 -> product_many, mpc-core rep3/arithmetic.rs:86-102): prod_j E_mems[j]
+ *   COZK_G_LTU     (sltu.rs:139-170): mems = C LTU memories then C - 1 EQ memories: sum_i ltu_i prod_{j<i} eq_j
+ * The last two multiply shared values: each level is ONE batched mul_vec over all active (index, instruction, point)
+ * items -- cozk_primary_level does the local half and names the device buffers of the ring exchange, which the host
+ * runs (cozk_reshare / its own transport) before the next call. */
+#define COZK_G_CONCAT 0
+#define COZK_G_PRODUCT 1
+#define COZK_G_LTU 2
+typedef struct cozk_primary cozk_primary;
+typedef struct cozk_primary_instr {
+    int form;    /* COZK_G_* */
+    int n_mems;  /* 1..8 */
+    int mems[8]; /* indices into the E polynomials */
+    int bits;    /* CONCAT: operand bits per chunk */
+} cozk_primary_instr;
+int cozk_primary_create(cozk_ctx* ctx, int mode, int party_id, const cozk_primary_instr* instrs, size_t n_instr,
+                        const cozk_vec* const* flags, const cozk_poly* const* E, size_t n_mem,
+                        const cozk_poly* lookup_outputs, const cozk_vec* eq, cozk_primary** out);
+int cozk_primary_free(cozk_primary* p);
+int cozk_primary_degree(const cozk_primary* p); /* sumcheck_poly_degree (worker.rs:701-708): max g degree + 2 */
+size_t cozk_primary_len(const cozk_primary* p);
+/* one round = primary_sumcheck_prover_message (worker.rs:454-598), in three steps:
+ * round_begin: bind with the previous challenge r (NULL in the first round), the pass over the linear instructions, the
+ *   item list of the multiplicative ones (*n_items; *n_levels mul_vec levels follow, 0 if there are no items);
+ * level (1 .. n_levels): local products + zero-sharing masks PRF(key_self, counter + j) - PRF(key_prev, counter + j) of
+ *   n_elems = n_items x degree elements; Rep3: exchange *send -> next party, previous party's -> *recv, then go on;
+ * round_finish: out_evals = degree x 4 u64, this party's additive evaluations at X = 0, 2, 3, .., degree. */
+int cozk_primary_round_begin(cozk_ctx* ctx, cozk_primary* p, const uint64_t* r, size_t* n_items, int* n_levels);
+int cozk_primary_level(cozk_ctx* ctx, cozk_primary* p, int level, const uint8_t* key_self, const uint8_t* key_prev,
+                       uint64_t counter, const void** send, void** recv, size_t* n_elems);
+int cozk_primary_round_finish(cozk_ctx* ctx, cozk_primary* p, uint64_t* out_evals);
+/* after the last round: bind with the last challenge; E_evals = n_mem x (a[4], b[4]), flag_evals = n_instr x 4 (public),
+ * out_eval = (a[4], b[4]), eq_eval[4] (may be NULL)  (worker.rs:427-452) */
+int cozk_primary_final_evals(cozk_ctx* ctx, cozk_primary* p, const uint64_t r[4], uint64_t* E_evals,
+                             uint64_t* flag_evals, uint64_t out_eval[8], uint64_t eq_eval[4]);
+
 /* SplitEqPolynomial::{new, bind} */
 int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out);
 int cozk_spliteq_free(cozk_spliteq* e);
@@ -531,10 +573,12 @@ typedef struct cozk_lookups_config {
     int density_pct; /* share of the flags that are set, 0..100 */
     int devices[3];
     uint64_t seed;
+    int primary; /* 1: run Lasso's primary sumcheck first (n_pairs E polynomials, a five-instruction synthetic table of the
+                    three collation forms, lookup_outputs = sum_i flag_i g_i(E)); the proof then starts with its part */
 } cozk_lookups_config;
 typedef struct cozk_lookups_result {
     int verified; /* 1 ok, 0 rejected, -1 not run */
-    double wall_ms, t_construct_ms, t_prove_ms, t_worker_ms;
+    double wall_ms, t_primary_ms, t_construct_ms, t_prove_ms, t_worker_ms;
     uint64_t bytes_star_up, bytes_star_down, bytes_ring, star_messages;
     uint64_t proof_len;
     uint8_t proof_digest[32];

@@ -3,6 +3,7 @@ Python over the SPARSE oracle (oracle/pysparse.py): same synthetic flags and fin
 serialization -- for small sizes the engine's proof must be bit-identical (plain prover and 3-party Rep3 run)."""
 import hashlib
 
+import pyprimary as P
 import pyref as O
 import pysparse as S
 
@@ -32,22 +33,61 @@ def serialize(proof):
     return out
 
 
+def instr_table(n_mem):
+    """lookups_harness.hpp lookups_instr_table: three CONCAT, one PRODUCT, one LTU instruction, memory indices mod n_mem"""
+    M = lambda xs: [x % n_mem for x in xs]
+    return [P.Instr(P.CONCAT, M([0, 1, 2, 3]), 8), P.Instr(P.CONCAT, M([4, 5, 6, 7]), 8), P.Instr(P.CONCAT, M([4, 1, 6, 3]), 4),
+            P.Instr(P.PRODUCT, M([8, 9, 10, 11])), P.Instr(P.LTU, M([12, 13, 14, 15, 16, 17, 18]))]
+
+
+def run_primary(cfg, tr, vt):
+    """the primary-sumcheck phase: returns (serialized part, verified)"""
+    nparties = 1 if cfg["mode"] == "plain" else 3
+    n = 1 << cfg["log_n"]
+    n_mem = cfg["n_pairs"]
+    seed = cfg["seed"]
+    instrs = instr_table(n_mem)
+    which = [v % len(instrs) for v in O.synthetic_small(seed + 1234567, n, 8)]
+    flags = [[1 if which[x] == i else 0 for x in range(n)] for i in range(len(instrs))]
+    Ep = [O.synthetic_fr(seed + 9000 * (m + 1), n) for m in range(n_mem)]
+    out = [P.g_plain(instrs[which[x]], [Ep[m][x] for m in instrs[which[x]].mems]) for x in range(n)]
+    if nparties == 1:
+        E, outs = [Ep], [out]
+    else:
+        Es = [O.rep3_share_vec(Ep[m], O.harness_prf_key(seed + 9000 * (m + 1), 101), O.harness_prf_key(seed + 9000 * (m + 1), 102)) for m in range(n_mem)]
+        E = [[Es[m][p] for m in range(n_mem)] for p in range(3)]
+        outs = O.rep3_share_vec(out, O.harness_prf_key(seed + 555, 101), O.harness_prf_key(seed + 555, 102))
+    r_eq = tr.challenge_vector(cfg["log_n"])
+    proof, rs, _fin = P.prove(instrs, r_eq, flags, E, outs, tr)
+    vr_eq = vt.challenge_vector(cfg["log_n"])
+    v = P.verify(instrs, vr_eq, proof, n_mem, vt)
+    ok = v == rs
+    if ok:  # openings == direct evaluations at the reversed challenge list
+        eq = O.eq_evals(list(reversed(rs)))
+        direct = [sum(a * b for a, b in zip(eq, poly)) % R for poly in Ep + flags + [out]]
+        ok = direct == proof["openings"]
+    blob = O.ser_u64(len(proof["round_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["round_polys"]) + O.ser_vec_fr(proof["openings"])
+    return blob, ok
+
+
 def run(cfg):
     nparties = 1 if cfg["mode"] == "plain" else 3
     n = 1 << cfg["log_n"]
     batch = 2 * cfg["n_pairs"]
     seed = cfg["seed"]
+    tr = O.Transcript(b"cozk-lookups")
+    vt = O.Transcript(b"cozk-lookups")
+    head, ok_primary = (run_primary(cfg, tr, vt) if cfg.get("primary") else (b"", True))
     cols = [flag_column(seed, q, n, cfg["density_pct"]) for q in range(cfg["n_pairs"])]
     flag_indices = [[i for i, f in enumerate(c) if f] for c in cols]
     per_circuit = [fingerprints_of(seed, b, n, nparties) for b in range(batch)]
     fps = [[per_circuit[b][p] for b in range(batch)] for p in range(nparties)]
     toggles, sparse = S.toggled_construct(flag_indices, fps)
-    tr = O.Transcript(b"cozk-lookups")
     proof, r = S.toggled_prove(toggles, sparse, tr)
-    v = S.toggled_verify(proof, O.Transcript(b"cozk-lookups"))
-    ok = v is not None
+    v = S.toggled_verify(proof, vt)
+    ok = v is not None and ok_primary
     if ok:
         plain = [O.synthetic_fr(seed + 7000 * (b + 1), n) for b in range(batch)]
         ok = (v[0], v[1]) == S.toggled_leaf_mles(flag_indices, plain, v[2]) and v[2] == r
-    blob = serialize(proof)
+    blob = head + serialize(proof)
     return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": ok, "proof": proof, "r": r}

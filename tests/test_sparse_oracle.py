@@ -134,3 +134,13 @@ def test_pipeline_oracle_small():
     a = pylookups.run(dict(mode="plain", log_n=3, n_pairs=3, density_pct=30, seed=9))
     b = pylookups.run(dict(mode="rep3", log_n=3, n_pairs=3, density_pct=30, seed=9))
     assert a["verified"] and a["digest"] == b["digest"]
+
+
+def test_primary_sumcheck_oracle_plain_equals_rep3_and_verifies():
+    """oracle/pyprimary.py: the three collation forms, 3-party lock-step with mul_vec reshares == the plain
+    prover; the verifier's final check and the openings hold; pipeline bytes of the two modes are identical"""
+    for log_n, n_pairs in ((1, 3), (3, 19), (4, 8)):
+        a = pylookups.run(dict(mode="plain", log_n=log_n, n_pairs=n_pairs, density_pct=30, seed=4, primary=1))
+        b = pylookups.run(dict(mode="rep3", log_n=log_n, n_pairs=n_pairs, density_pct=30, seed=4, primary=1))
+        assert a["verified"] and b["verified"]
+        assert a["proof_bytes"] == b["proof_bytes"]
