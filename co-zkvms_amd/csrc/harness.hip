@@ -1066,3 +1066,4 @@ int cozk_worker_spartan_second_sumcheck(cozk_ctx* ctx, const cozk_worker_params*
 // --------------------------------------------------------------------------- co-noir-spartan harness (config 4)
 #include "host/spartan_harness.hpp"
 #include "host/lookups_harness.hpp"
+#include "host/outer_harness.hpp"

@@ -818,6 +818,111 @@ static bool verify_primary_sumcheck(const PrimarySumcheckProof& proof, const std
     return Fr::eq(Fr::mul(eq, Fr::sub(acc, proof.openings.back())), claim);
 }
 
+// ================================================================= co-jolt Spartan outer sumcheck
+struct OuterH {
+    cozk_outer* h = nullptr;
+    OuterH() {}
+    explicit OuterH(cozk_outer* p) : h(p) {}
+    OuterH(const OuterH&) = delete;
+    OuterH& operator=(const OuterH&) = delete;
+    ~OuterH() { cozk_outer_free(h); }
+};
+
+// prove_spartan_cubic_sumcheck (co-jolt/src/r1cs/spartan/worker.rs:277-300): per round the cubic goes up
+// (process_eq_sumcheck_round_worker, subprotocols/sumcheck_spartan.rs:44-79), (next claim, r_i) comes down; at the end the
+// three final evaluations.  Returns the challenges in round order.
+static std::vector<fe> prove_spartan_cubic_sumcheck_worker(WorkerEnv& env, cozk_outer* st, int num_rounds) {
+    std::vector<fe> rs;
+    fe claim = Fr::zero();
+    uint64_t rr[4];
+    for (int round = 0; round < num_rounds; round++) {
+        uint64_t cl[4], cf[16];
+        fe_to_u64x4(claim, cl);
+        rc_check(cozk_outer_round(env.ctx, st, round ? rr : nullptr, cl, cf), env.ctx, "outer_round");
+        std::vector<fe> poly(4);
+        for (int i = 0; i < 4; i++) poly[i] = fe_from_u64x4(cf + 4 * i);
+        Writer w;
+        w.vec_fr(poly);
+        env.star->send_response(w.b);
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        fe next_claim = rd.fr();
+        fe r_i = rd.fr();
+        rs.push_back(r_i);
+        claim = env.additive_trivial(next_claim);
+        fe_to_u64x4(r_i, rr);
+    }
+    uint64_t fin[12];
+    rc_check(cozk_outer_final_evals(env.ctx, st, rr, fin), env.ctx, "outer_final_evals");
+    std::vector<fe> ev(3);
+    for (int i = 0; i < 3; i++) ev[i] = fe_from_u64x4(fin + 4 * i);
+    Writer w;
+    w.vec_fr(ev);
+    env.star->send_response(w.b);
+    return rs;
+}
+
+struct OuterSumcheckProof {
+    std::vector<std::vector<fe>> compressed_polys;
+    std::vector<fe> claims;  // Az(r), Bz(r), Cz(r)
+};
+
+// coordinate_eq_sumcheck_round (subprotocols/sumcheck_spartan.rs:14-42) over all rounds + the outer claims
+// (r1cs/spartan/coordinator.rs:41-63)
+static OuterSumcheckProof coordinate_outer_sumcheck(StarNetCoordinator& net, Transcript& tr, int num_rounds, std::vector<fe>& r_out) {
+    OuterSumcheckProof proof;
+    r_out.clear();
+    for (int round = 0; round < num_rounds; round++) {
+        std::vector<std::vector<fe>> parts;
+        for (Bytes& b : net.receive_responses()) {
+            Reader rd(b);
+            parts.push_back(rd.vec_fr());
+        }
+        std::vector<fe> poly = combine_additive(parts);
+        std::vector<fe> comp = unipoly_compress(poly);
+        tr.append_scalars(comp);
+        proof.compressed_polys.push_back(comp);
+        fe r_i = tr.challenge_scalar();
+        r_out.push_back(r_i);
+        fe claim = unipoly_eval(poly, r_i);
+        Writer w;
+        w.fr(claim);
+        w.fr(r_i);
+        net.broadcast_request(w.b);
+    }
+    std::vector<std::vector<fe>> parts;
+    for (Bytes& b : net.receive_responses()) {
+        Reader rd(b);
+        parts.push_back(rd.vec_fr());
+    }
+    proof.claims = combine_additive(parts);
+    tr.append_scalars(proof.claims);
+    return proof;
+}
+
+// outer-sumcheck part of the plain verifier (jolt-core UniformSpartanProof::verify, out of tree)
+static bool verify_outer_sumcheck(const OuterSumcheckProof& proof, const std::vector<fe>& tau, Transcript& tr, std::vector<fe>& r_out) {
+    fe claim = Fr::zero();
+    r_out.clear();
+    for (const auto& comp : proof.compressed_polys) {
+        if (comp.size() != 3) return false;
+        std::vector<fe> poly = unipoly_decompress(comp, claim);
+        tr.append_scalars(comp);
+        fe r_i = tr.challenge_scalar();
+        r_out.push_back(r_i);
+        claim = unipoly_eval(poly, r_i);
+    }
+    if (proof.claims.size() != 3 || r_out.size() != tau.size()) return false;
+    tr.append_scalars(proof.claims);
+    fe one = Fr::one(), eq = one;
+    for (size_t i = 0; i < tau.size(); i++) {
+        const fe& a = tau[i];
+        const fe& b = r_out[r_out.size() - 1 - i];
+        eq = Fr::mul(eq, Fr::add(Fr::sub(Fr::sub(one, a), b), Fr::dbl(Fr::mul(a, b))));
+    }
+    return Fr::eq(Fr::mul(eq, Fr::sub(Fr::mul(proof.claims[0], proof.claims[1]), proof.claims[2])), claim);
+}
+
 // ================================================================= PST13
 struct PST13Commitment {
     uint64_t nv;

@@ -362,6 +362,46 @@ int cozk_primary_round_finish(cozk_ctx* ctx, cozk_primary* p, uint64_t* out_eval
 int cozk_primary_final_evals(cozk_ctx* ctx, cozk_primary* p, const uint64_t r[4], uint64_t* E_evals,
                              uint64_t* flag_evals, uint64_t out_eval[8], uint64_t eq_eval[4]);
 
+/* ---- co-jolt's Spartan outer sumcheck over Az / Bz / Cz (co-jolt/src/poly/spartan_interleaved_poly.rs,
+ * co-jolt/src/r1cs/spartan/worker.rs:63-120,277-300):  sum_x eq(tau, x) (Az(x) Bz(x) - Cz(x)) = 0.
+ * The constraint system is an input (the concrete Jolt constraints live in jolt-core): linear combinations over the
+ * witness columns (`flattened_polynomials`, one entry per step each), as jolt-core's r1cs builder holds them:
+ *   uniform constraint i (Constraint {a, b, c}):           row i of a step:  Az = a.z, Bz = b.z, Cz = c.z
+ *   cross-step constraint j (OffsetEqConstraint {cond, a, b}): Az = a.z - b.z, Bz = cond.z, Cz = 0, where an LC with
+ *   offset != 0 reads the NEXT step (its constant term only at the last step; spartan_interleaved_poly.rs:666-684).
+ * Az, Bz, Cz live as dense share arrays over rows = step * padded_num_constraints + constraint (a public column enters as
+ * its trivial share), built on the device straight from the columns. */
+typedef struct cozk_lc {
+    int first_term; /* terms [first_term, first_term + n_terms) of the system's term arrays */
+    int n_terms;
+    int offset;
+} cozk_lc;
+typedef struct cozk_r1cs {
+    const int* term_var;       /* column index, or -1 for the constant */
+    const int64_t* term_coeff; /* small integer coefficients (F::from_i64) */
+    size_t n_terms;
+    const cozk_lc* uniform;    /* 3 per constraint: a, b, c */
+    size_t n_uniform;
+    const cozk_lc* cross;      /* 3 per constraint: a, b, cond */
+    size_t n_cross;
+    size_t padded_num_constraints; /* rows per step: a power of two >= n_uniform + n_cross */
+} cozk_r1cs;
+typedef struct cozk_outer cozk_outer;
+/* compute_spartan_Az_Bz_Cz + GruenSplitEqPolynomial::new(tau); vars: REP3 polynomials are shared columns, PLAIN ones
+ * public; tau = log2(steps * padded_num_constraints) challenges */
+int cozk_outer_create(cozk_ctx* ctx, int mode, int party_id, const cozk_r1cs* sys, const cozk_poly* const* vars,
+                      size_t n_vars, const uint64_t* tau, size_t n_tau, cozk_outer** out);
+int cozk_outer_free(cozk_outer* st);
+size_t cozk_outer_len(const cozk_outer* st);
+int cozk_outer_download(cozk_ctx* ctx, const cozk_outer* st, uint64_t* az_a, uint64_t* az_b, uint64_t* bz_a,
+                        uint64_t* bz_b, uint64_t* cz_a, uint64_t* cz_b);
+/* first_sumcheck_round / subsequent_sumcheck_round (spartan_interleaved_poly.rs:189-612) without the network leg: bind with
+ * the previous challenge r (NULL in the first round), then the cubic round polynomial of
+ * process_eq_sumcheck_round_worker (subprotocols/sumcheck_spartan.rs:44-79) as 4 additive coefficient shares */
+int cozk_outer_round(cozk_ctx* ctx, cozk_outer* st, const uint64_t* r, const uint64_t claim[4], uint64_t out_coeffs[16]);
+/* final_sumcheck_evals (:648-664) after binding with the last challenge: additive Az(r), Bz(r), Cz(r) */
+int cozk_outer_final_evals(cozk_ctx* ctx, cozk_outer* st, const uint64_t r[4], uint64_t out[12]);
+
 /* SplitEqPolynomial::{new, bind} */
 int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out);
 int cozk_spliteq_free(cozk_spliteq* e);
@@ -588,6 +628,30 @@ const char* cozk_lookups_error(const cozk_lookups* h);
 int cozk_lookups_destroy(cozk_lookups* h);
 int cozk_lookups_prove(cozk_lookups* h, int verify, cozk_lookups_result* res);
 int cozk_lookups_proof_bytes(const cozk_lookups* h, uint8_t* out, size_t cap);
+
+/* ---------------------------------------------------------------- Spartan outer-sumcheck harness ---- */
+/* SURVEY.md 8(f)2 restated synthetically: Az / Bz / Cz of a satisfied constraint system over 14 witness columns (shared and
+ * public; 5 uniform + 2 cross-step constraints, 8 rows per step; csrc/host/outer_harness.hpp) and co-jolt's outer cubic
+ * sumcheck with the Gruen split-eq (r1cs/spartan/worker.rs:63-100,277-300); coordinator + plain verifier on the caller. */
+typedef struct cozk_outer_harness cozk_outer_harness;
+typedef struct cozk_outer_config {
+    int mode;
+    int log_steps; /* steps (cycles) = 2^log_steps; rows = 8 * steps */
+    int devices[3];
+    uint64_t seed;
+} cozk_outer_config;
+typedef struct cozk_outer_result {
+    int verified;
+    double wall_ms, t_build_ms, t_prove_ms, t_worker_ms;
+    uint64_t bytes_star_up, bytes_star_down, star_messages;
+    uint64_t proof_len;
+    uint8_t proof_digest[32];
+} cozk_outer_result;
+int cozk_outer_harness_create(const cozk_outer_config* cfg, cozk_outer_harness** out);
+const char* cozk_outer_harness_error(const cozk_outer_harness* h);
+int cozk_outer_harness_destroy(cozk_outer_harness* h);
+int cozk_outer_harness_prove(cozk_outer_harness* h, int verify, cozk_outer_result* res);
+int cozk_outer_harness_proof_bytes(const cozk_outer_harness* h, uint8_t* out, size_t cap);
 
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation, k_msm_accum0) on the ctx stream,

@@ -144,3 +144,13 @@ def test_primary_sumcheck_oracle_plain_equals_rep3_and_verifies():
         b = pylookups.run(dict(mode="rep3", log_n=log_n, n_pairs=n_pairs, density_pct=30, seed=4, primary=1))
         assert a["verified"] and b["verified"]
         assert a["proof_bytes"] == b["proof_bytes"]
+
+
+def test_spartan_outer_oracle_verifies_and_plain_equals_rep3():
+    """oracle/pyspartan_outer.py: the sparse SharedOrPublic walk with the Gruen split-eq verifies, its claims
+    are the multilinear extensions of the clear Az, Bz, Cz, and the plain and the 3-party run give the same bytes"""
+    import pyspartan_outer as SO
+    for ls in (0, 1, 3, 4):
+        a = SO.run(dict(mode="plain", log_steps=ls, seed=3))
+        b = SO.run(dict(mode="rep3", log_steps=ls, seed=3))
+        assert a["verified"] and b["verified"] and a["proof_bytes"] == b["proof_bytes"]
