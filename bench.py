@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--host-witness", action="store_true",
                     help="also time the H2D upload of a host-resident witness of the same size (pinned memory) and report the "
                          "PCIe-inclusive step beside `value` (which never includes PCIe)")
+    ap.add_argument("--witness-scatter", action="store_true",
+                    help="also time the device-to-device witness scatter (SURVEY 8(f)3): Rep3 shares of the 64 Fr polynomials for three "
+                         "parties generated on the dealer's GPU and delivered into the parties' contexts (cozk_rep3_scatter)")
     ap.add_argument("--hub", choices=["shm", "gloo"], default="shm", help="transport of the per-round star messages (--shard worker)")
     ap.add_argument("--shard", choices=["worker", "segment"], default="worker",
                     help="N>1: one proof sharded as worker sub-nets (default) or N independent trace segments")
@@ -284,6 +287,9 @@ def run_rank(args):
     if args.host_witness and rank == 0 and world == 1:
         out["host_witness"] = _host_witness_leg(pkg, torch, dev, log_n, ms_per_step)
 
+    if args.witness_scatter and rank == 0 and world == 1:
+        out["witness_scatter"] = _witness_scatter_leg(pkg, torch, dev, log_n)
+
     # ---- CPU baseline (rank 0, N = 1 only): the oracle's C restatement on a bounded sample
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
@@ -340,6 +346,40 @@ def _host_witness_leg(pkg, torch, dev, log_n, ms_per_step):
             "ms_per_step_incl_upload": round(ms_per_step + up_ms, 3),
             "value_incl_upload": round((1 << log_n) / ((ms_per_step + up_ms) * 1e-3), 1),
             "note": "pinned host memory, uploads serialized before the step (no overlap); `value` above excludes this"}
+
+
+def _witness_scatter_leg(pkg, torch, dev, log_n, n_polys=64):
+    """the reference's `init` phase (receive_witness_share: 71 s at 2^20) restated device to device: for each
+    of the 64 Fr polynomials the dealer's context generates the three parties' Rep3 components (keyed ChaCha12 PRF) and
+    they land in the parties' contexts -- on their own GPUs when >= 3 (or >= 2) are visible, else on this one"""
+    n = 1 << log_n
+    ndev = torch.cuda.device_count()
+    devs = [dev, (dev + 1) % ndev, (dev + 2) % ndev] if ndev >= 3 else [dev] * 3
+    dealer = pkg.Context(dev)
+    parties = [pkg.Context(d) for d in devs]
+    secret = [pkg.Vec.random(dealer, n, seed=900 + i) for i in range(4)]  # four distinct secrets, reused round-robin
+    k0, k1 = bytes(range(32)), bytes(range(32, 64))
+    best = None
+    for _ in range(3):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for i in range(n_polys):
+            for p in range(3):
+                a, b = secret[i % 4].rep3_scatter(k0, k1, p, parties[p], counter=i * n)
+                a.free()
+                b.free()
+        for c in parties:
+            c.synchronize()
+        dt = time.perf_counter() - t0
+        best = dt if best is None else min(best, dt)
+    nbytes = n_polys * 3 * 2 * n * 32
+    for c in parties:
+        c.close()
+    dealer.close()
+    return {"polys": n_polys, "parties": 3, "party_devices": devs, "share_bytes_delivered": nbytes, "ms": round(best * 1e3, 3),
+            "GBps_delivered": round(nbytes / best / 1e9, 1),
+            "note": "shares generated on the dealer's GPU (ChaCha12 PRF, 2 blocks per element) and written into the parties' contexts; "
+                    "peer copies over xGMI when the parties have GPUs of their own; not part of `value`"}
 
 
 if __name__ == "__main__":

@@ -118,6 +118,7 @@ SIGNATURES = {
     "cozk_layer_compute_cubic": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_ctx_set_resident_rounds": (_i, [_vp, _i]),
     "cozk_rep3_share_vec": (_i, [_vp, _vp, ctypes.c_char_p, ctypes.c_char_p, _u64, _i, _pp, _pp]),
+    "cozk_rep3_scatter": (_i, [_vp, _vp, ctypes.c_char_p, ctypes.c_char_p, _u64, _vp, _i, _pp, _pp]),
     "cozk_vec_fill_prf": (_i, [_vp, _vp, ctypes.c_char_p, _u64]),
     "cozk_layer_round": (_i, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "cozk_fingerprint_leaves": (_i, [_vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _i, _i, _vp, _vp, _sz, _sz]),

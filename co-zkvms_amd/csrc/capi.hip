@@ -280,6 +280,50 @@ int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, const uint8_t key0[COZ
     });
 }
 
+// The witness scatter, device to device (jolt/vm/jolt/coordinator.rs:72-91 + receive_witness_share, jolt/vm/*/witness.rs):
+// the dealer's context holds the secret vector; `party`'s Rep3 components are generated on the dealer's GPU and land in
+// vectors owned by the PARTY's context -- written in place when both contexts share a device, otherwise generated into the
+// dealer's memory and moved with one peer copy per component (xGMI on an MI355X node).  Nothing crosses the host; the
+// reference serialises 64-byte shares through QUIC (init = 71 s at 2^20).
+int cozk_rep3_scatter(cozk_ctx* dealer, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES], const uint8_t key1[COZK_PRF_KEY_BYTES],
+                      uint64_t counter, cozk_ctx* party_ctx, int party, cozk_vec** out_a, cozk_vec** out_b) {
+    if (!out_a || !out_b || !party_ctx) return COZK_ERR_INVALID_ARG;
+    *out_a = *out_b = nullptr;
+    int rc = cozk_guard(dealer, [&] {
+        COZK_REQUIRE(dealer && v && key0 && key1 && v->kind == COZK_SCALAR_FR && party >= 0 && party < 3, "rep3_scatter: bad argument");
+    });
+    if (rc != COZK_OK) return rc;
+    rc = cozk_vec_alloc(party_ctx, v->n, COZK_SCALAR_FR, out_a);
+    if (rc == COZK_OK) rc = cozk_vec_alloc(party_ctx, v->n, COZK_SCALAR_FR, out_b);
+    if (rc == COZK_OK)
+        rc = cozk_guard(dealer, [&] {
+            const size_t n = v->n;
+            if (n == 0) return;
+            const bool same = dealer->device == party_ctx->device;
+            fe *da = (fe*)(*out_a)->d, *db = (fe*)(*out_b)->d;
+            fe *sa = da, *sb = db;
+            if (!same) {
+                sa = (fe*)ctx_dev_alloc(dealer, 2 * n * sizeof(fe));
+                sb = sa + n;
+            }
+            k_rep3_share<<<(unsigned)((n + 255) / 256), 256, 0, dealer->stream>>>((const fe*)v->d, n, prf_key_from_bytes(key0), prf_key_from_bytes(key1), counter,
+                                                                              party, sa, sb);
+            HIP_TRY(hipGetLastError());
+            if (!same) {
+                HIP_TRY(hipMemcpyPeerAsync(da, party_ctx->device, sa, dealer->device, n * sizeof(fe), dealer->stream));
+                HIP_TRY(hipMemcpyPeerAsync(db, party_ctx->device, sb, dealer->device, n * sizeof(fe), dealer->stream));
+            }
+            HIP_TRY(hipStreamSynchronize(dealer->stream));  // the party's stream may use the shares as soon as this returns
+            if (!same) ctx_dev_free(dealer, sa);
+        });
+    if (rc != COZK_OK) {
+        cozk_vec_free(*out_a);
+        cozk_vec_free(*out_b);
+        *out_a = *out_b = nullptr;
+    }
+    return rc;
+}
+
 int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits) {
     return cozk_guard(ctx, [&] {
         COZK_REQUIRE(ctx && v, "vec_fill_random: bad argument");

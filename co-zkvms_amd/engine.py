@@ -257,6 +257,14 @@ class Vec:
                                                        ctypes.byref(a), ctypes.byref(b)))
         return Vec(self.ctx, a, L.SCALAR_FR), Vec(self.ctx, b, L.SCALAR_FR)
 
+    def rep3_scatter(self, key0, key1, party, party_ctx, counter=0):
+        """the witness scatter device to device (cozk_rep3_scatter): this (dealer-side) secret vector's shares for `party`,
+        as vectors owned by `party_ctx` (same or another GPU)"""
+        a, b = ctypes.c_void_p(), ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_rep3_scatter(self.ctx.h, self.h, L.prf_key(key0), L.prf_key(key1), counter, party_ctx.h, party,
+                                                     ctypes.byref(a), ctypes.byref(b)))
+        return Vec(party_ctx, a, L.SCALAR_FR), Vec(party_ctx, b, L.SCALAR_FR)
+
     @classmethod
     def prf(cls, ctx, n, key, counter=0):
         """out[i] = PRF(key, counter + i): the keyed ChaCha12 stream every share / mask is drawn from"""

@@ -105,6 +105,13 @@ int cozk_vec_fill_prf(cozk_ctx* ctx, cozk_vec* v, const uint8_t key[COZK_PRF_KEY
 int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES],
                         const uint8_t key1[COZK_PRF_KEY_BYTES], uint64_t counter, int party,
                         cozk_vec** out_a, cozk_vec** out_b);
+/* The witness scatter device to device (jolt/vm/jolt/coordinator.rs:72-91; receive_witness_share in jolt/vm/.../witness.rs):
+ * as cozk_rep3_share_vec, but the secret lives on the DEALER's context and the outputs are vectors of `party_ctx` (another
+ * GPU, or the same one): generated on the dealer's device, moved by a peer copy over xGMI when the devices differ.
+ * Returns after the copy has completed. */
+int cozk_rep3_scatter(cozk_ctx* dealer, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES],
+                      const uint8_t key1[COZK_PRF_KEY_BYTES], uint64_t counter, cozk_ctx* party_ctx, int party,
+                      cozk_vec** out_a, cozk_vec** out_b);
 /* element-wise out[i] = a[i] (op) b[i] on 32-byte field elements: the local arithmetic of
  * mpc-types/src/protocols/additive/ops.rs (AdditivePrimeFieldShare is repr(transparent) over F).
  * base_field = 0: Fr (scalar field, what shares live in); 1: Fq (G1 coordinate field). */

@@ -174,3 +174,26 @@ def test_rep3_share_vec_matches_oracle_sharing(cozk, ctx):
         got.append((a.to_ints(), b.to_ints()))
         assert got[p] == ([x[0] for x in exp[p]], [x[1] for x in exp[p]])
     assert [(x + y + z) % O.R for x, y, z in zip(got[0][0], got[1][0], got[2][0])] == v
+
+
+def test_rep3_scatter_device_to_device(cozk, ctx):
+    """cozk_rep3_scatter: the dealer's context generates a party's shares and they arrive as vectors of the PARTY's context
+    (another context on the same GPU here; a peer copy over xGMI when the devices differ -- 2 GPUs needed for that leg):
+    equal to cozk_rep3_share_vec / the oracle, usable by the party's own stream right away"""
+    import torch
+    n = 1000
+    v = O.synthetic_fr(808, n)
+    V = cozk.Vec.from_ints(ctx, v)
+    k0, k1 = O.harness_prf_key(61, 0), O.harness_prf_key(62, 0)
+    exp = O.rep3_share_vec(v, k0, k1, counter=4)
+    devs = [0] + ([1] if torch.cuda.device_count() > 1 else [])
+    for d in devs:
+        party_ctx = cozk.Context(d)
+        for p in range(3):
+            a, b = V.rep3_scatter(k0, k1, p, party_ctx, counter=4)
+            assert a.ctx is party_ctx
+            assert (a.to_ints(), b.to_ints()) == ([x[0] for x in exp[p]], [x[1] for x in exp[p]])
+            assert a.binop(cozk.OP_ADD, b).to_ints() == [(x[0] + x[1]) % O.R for x in exp[p]]  # the party computes on them
+            a.free()
+            b.free()
+        party_ctx.close()
