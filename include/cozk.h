@@ -409,6 +409,31 @@ int cozk_outer_round(cozk_ctx* ctx, cozk_outer* st, const uint64_t* r, const uin
 /* final_sumcheck_evals (:648-664) after binding with the last challenge: additive Az(r), Bz(r), Cz(r) */
 int cozk_outer_final_evals(cozk_ctx* ctx, cozk_outer* st, const uint64_t r[4], uint64_t out[12]);
 
+/* ---- co-noir-spartan's public lookup round (co-noir-spartan/co-spartan/src/worker.rs:400-575,694-724,836-846;
+ * co-noir-spartan/spartan/src/logup.rs:31-80; co-spartan/src/sumcheck.rs:434-500): plain Fr data, no shares. */
+/* hash_tuple (worker.rs:836-846): out[j] = idx[j] + v_msg * eq[idx[j]] for the (pre-filtered) indices, the tail up to n_out
+ * (a power of two) repeats entry 0 */
+int cozk_hash_tuple(cozk_ctx* ctx, const cozk_vec* idx_u32, const cozk_vec* eq, const uint64_t v_msg[4], size_t n_out,
+                    cozk_vec** out);
+/* LogLookupProof::prove's field work (logup.rs:45-70): phi = x + values, h = m / phi (m = NULL: 1 / phi) */
+int cozk_logup_h(cozk_ctx* ctx, const cozk_vec* values, const cozk_vec* m, const uint64_t x[4], cozk_vec** out_phi,
+                 cozk_vec** out_h);
+/* boost_degree (spartan/src/utils.rs:11-27): scale by 2^-(new_num_vars - num_vars) and repeat up to 2^new_num_vars */
+int cozk_vec_boost_degree(cozk_ctx* ctx, const cozk_vec* v, int new_num_vars, cozk_vec** out);
+/* distributed_sumcheck_worker's prover (worker.rs:694-724) = ark-linear-sumcheck IPForMLSumcheck::{prover_init,
+ * prove_round} over a ListOfProductsOfPolynomials: product q = coefs[q] * prod of counts[q] polynomials
+ * (factor_idx lists them product after product; <= 48 polynomials, <= 32 products, <= 4 factors) */
+typedef struct cozk_prodlist cozk_prodlist;
+int cozk_prodlist_create(cozk_ctx* ctx, const cozk_vec* const* polys, size_t n_polys, const uint64_t* coefs,
+                         const int* counts, const int* factor_idx, size_t n_terms, cozk_prodlist** out);
+int cozk_prodlist_free(cozk_prodlist* pl);
+int cozk_prodlist_degree(const cozk_prodlist* pl); /* max_multiplicands */
+/* prove_round: fix_variables with the previous randomness r (NULL in the first round), then out_evals =
+ * (degree + 1) x 4 u64: the evaluations at t = 0 .. degree */
+int cozk_prodlist_round(cozk_ctx* ctx, cozk_prodlist* pl, const uint64_t* r, uint64_t* out_evals);
+/* the last fix_variables + obtain_distrbuted_sumcheck_prover_state (sumcheck.rs:434-452): n_polys x 4 u64 */
+int cozk_prodlist_final(cozk_ctx* ctx, cozk_prodlist* pl, const uint64_t r[4], uint64_t* out_vals);
+
 /* SplitEqPolynomial::{new, bind} */
 int cozk_spliteq_new(cozk_ctx* ctx, const uint64_t* w, int nv, cozk_spliteq** out);
 int cozk_spliteq_free(cozk_spliteq* e);
