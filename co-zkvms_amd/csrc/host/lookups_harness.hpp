@@ -213,7 +213,8 @@ struct LookupsProof {
     }
 };
 
-void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star, RingNet* ring) {
+// star: this party's channel of the grand-product phase; pstars: its 2^log_workers channels of the primary sumcheck
+void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star, const std::vector<StarNetWorker*>& pstars, RingNet* ring) {
     const cozk_lookups_config& c = h->cfg;
     WorkerEnv env;
     env.ctx = ps.ctx;
@@ -227,23 +228,146 @@ void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star,
     double tp0 = now_ms();
     if (c.primary) {
         // ---- Lasso primary sumcheck (jolt/vm/instruction_lookups/worker.rs:95-141): r_eq from the coordinator, eq table,
-        //      then prove_primary_sumcheck_inner
-        Bytes req = env.star->receive_request();
-        Reader rd(req);
-        std::vector<fe> r_eq = rd.vec_fr();
-        std::vector<uint64_t> w = to_abi(r_eq);
+        //      then prove_primary_sumcheck (:180-373), split over 2^log_workers worker sub-nets
+        const int W = 1 << c.log_workers;
+        std::vector<fe> r_eq;
+        for (int w = 0; w < W; w++) {
+            Bytes req = pstars[w]->receive_request();
+            Reader rd(req);
+            r_eq = rd.vec_fr();
+        }
+        std::vector<uint64_t> wabi = to_abi(r_eq);
         cozk_vec* eqv = nullptr;
-        rc_check(cozk_eq_evals(env.ctx, w.data(), (int)r_eq.size(), &eqv), env.ctx, "eq_evals");
+        rc_check(cozk_eq_evals(env.ctx, wabi.data(), (int)r_eq.size(), &eqv), env.ctx, "eq_evals");
         VecH eqh(eqv);
-        std::vector<const cozk_vec*> fl;
-        for (auto& f : ps.instr_flags) fl.push_back(f.h);
-        std::vector<const cozk_poly*> E;
-        for (auto& e : ps.E) E.push_back(e.h);
-        cozk_primary* pr = nullptr;
-        rc_check(cozk_primary_create(env.ctx, c.mode, ps.party, h->instrs.data(), h->instrs.size(), fl.data(), E.data(), E.size(), ps.outputs.h, eqh.h, &pr),
-                 env.ctx, "primary_create");
-        PrimaryH prh(pr);
-        (void)prove_primary_sumcheck_worker(env, pr, c.log_n, E.size(), h->instrs.size());
+        const size_t n_mem = ps.E.size(), n_instr = h->instrs.size();
+        const size_t chunk = h->N >> c.log_workers;
+        // split_poly (worker.rs:213-235): worker w gets the w-th high-variable chunk of every polynomial -- zero-copy views
+        std::vector<PrimaryH> prims;
+        std::vector<std::vector<PolyH>> views((size_t)W);
+        for (int w = 0; w < W; w++) {
+            const size_t off = (size_t)w * chunk;
+            std::vector<cozk_vec> fv(n_instr);
+            std::vector<const cozk_vec*> fl;
+            for (size_t i = 0; i < n_instr; i++) {
+                fv[i] = *ps.instr_flags[i].h;
+                fv[i].d = (uint8_t*)fv[i].d + off;
+                fv[i].n = chunk;
+                fv[i].bytes = chunk;
+                fv[i].owned = false;
+                fl.push_back(&fv[i]);
+            }
+            std::vector<const cozk_poly*> E;
+            for (auto& e : ps.E) {
+                cozk_poly* v = nullptr;
+                rc_check(cozk_poly_chunk(env.ctx, e.h, off, chunk, &v), env.ctx, "poly_chunk");
+                views[w].push_back(PolyH(v));
+                E.push_back(v);
+            }
+            cozk_poly* ov = nullptr;
+            rc_check(cozk_poly_chunk(env.ctx, ps.outputs.h, off, chunk, &ov), env.ctx, "poly_chunk");
+            views[w].push_back(PolyH(ov));
+            cozk_vec ev = *eqh.h;
+            ev.d = (fe*)ev.d + off;
+            ev.n = chunk;
+            ev.bytes = chunk * sizeof(fe);
+            ev.owned = false;
+            cozk_primary* pr = nullptr;
+            rc_check(cozk_primary_create(env.ctx, c.mode, ps.party, h->instrs.data(), n_instr, fl.data(), E.data(), n_mem, ov, &ev, &pr), env.ctx, "primary_create");
+            prims.emplace_back(pr);
+        }
+        if (W == 1) {
+            env.star = pstars[0];
+            (void)prove_primary_sumcheck_worker(env, prims[0].h, c.log_n, n_mem, n_instr);
+        } else {
+            // the first log_n - log_workers rounds: every sub-net answers each round (worker.rs:237-300); the party's
+            // workers are time-sliced on this context, one GPU each in a real deployment
+            const int D = cozk_primary_degree(prims[0].h);
+            const int split_rounds = c.log_n - c.log_workers;
+            uint64_t rr[4];
+            for (int round = 0; round < split_rounds; round++) {
+                for (int w = 0; w < W; w++) {
+                    size_t n_items = 0;
+                    int n_levels = 0;
+                    rc_check(cozk_primary_round_begin(env.ctx, prims[w].h, round ? rr : nullptr, &n_items, &n_levels), env.ctx, "primary_round_begin");
+                    for (int level = 1; level <= n_levels; level++) {
+                        const void* send = nullptr;
+                        void* recv = nullptr;
+                        size_t n = 0;
+                        rc_check(cozk_primary_level(env.ctx, prims[w].h, level, env.key_self, env.key_prev, env.mask_ctr, &send, &recv, &n), env.ctx, "primary_level");
+                        if (env.mode == COZK_MODE_REP3) {
+                            env.ring->reshare(env.ctx, (const fe*)send, (fe*)recv, n);
+                            env.mask_ctr += n;
+                        }
+                    }
+                    std::vector<uint64_t> ev(4 * (size_t)D);
+                    rc_check(cozk_primary_round_finish(env.ctx, prims[w].h, ev.data()), env.ctx, "primary_round_finish");
+                    std::vector<fe> msg((size_t)D);
+                    for (int k = 0; k < D; k++) msg[k] = fe_from_u64x4(ev.data() + 4 * k);
+                    Writer wr;
+                    wr.vec_fr(msg);
+                    pstars[w]->send_response(wr.b);
+                }
+                for (int w = 0; w < W; w++) {
+                    Bytes req = pstars[w]->receive_request();
+                    Reader rd(req);
+                    fe_to_u64x4(rd.fr(), rr);
+                }
+            }
+            // every worker's final values become entry w of the 2^log_workers-long polynomials of the remaining rounds
+            // (worker.rs:301-345), which worker 0 proves (:347-372)
+            std::vector<fe> eq_rem((size_t)W);
+            std::vector<std::vector<fe>> fl_rem(n_instr, std::vector<fe>((size_t)W));
+            std::vector<std::vector<fe>> Ea(n_mem, std::vector<fe>((size_t)W)), Eb(n_mem, std::vector<fe>((size_t)W));
+            std::vector<fe> oa((size_t)W), ob((size_t)W);
+            for (int w = 0; w < W; w++) {
+                std::vector<uint64_t> Ee(8 * n_mem), Fe(4 * n_instr);
+                uint64_t oe[8], qe[4];
+                rc_check(cozk_primary_final_evals(env.ctx, prims[w].h, rr, Ee.data(), Fe.data(), oe, qe), env.ctx, "primary_final_evals");
+                eq_rem[w] = fe_from_u64x4(qe);
+                for (size_t i = 0; i < n_instr; i++) fl_rem[i][w] = fe_from_u64x4(Fe.data() + 4 * i);
+                for (size_t m = 0; m < n_mem; m++) {
+                    Ea[m][w] = fe_from_u64x4(Ee.data() + 8 * m);
+                    Eb[m][w] = fe_from_u64x4(Ee.data() + 8 * m + 4);
+                }
+                oa[w] = fe_from_u64x4(oe);
+                ob[w] = fe_from_u64x4(oe + 4);
+            }
+            auto up = [&](const std::vector<fe>& v) {
+                cozk_vec* d = nullptr;
+                rc_check(cozk_vec_upload(env.ctx, v.data(), v.size(), COZK_SCALAR_FR, &d), env.ctx, "vec_upload");
+                return VecH(d);
+            };
+            auto mkpoly = [&](const std::vector<fe>& a, const std::vector<fe>& b) {
+                VecH va = up(a), vb;
+                if (c.mode == COZK_MODE_REP3) vb = up(b);
+                cozk_poly* p = nullptr;
+                rc_check(cozk_poly_create(env.ctx, c.mode, va.h, vb.h, &p), env.ctx, "poly_create");
+                return PolyH(p);
+            };
+            std::vector<VecH> flv;
+            std::vector<const cozk_vec*> flp;
+            for (size_t i = 0; i < n_instr; i++) {
+                flv.push_back(up(fl_rem[i]));
+                flp.push_back(flv.back().h);
+            }
+            std::vector<PolyH> Er;
+            std::vector<const cozk_poly*> Ep;
+            for (size_t m = 0; m < n_mem; m++) {
+                Er.push_back(mkpoly(Ea[m], Eb[m]));
+                Ep.push_back(Er.back().h);
+            }
+            PolyH outr = mkpoly(oa, ob);
+            VecH eqr = up(eq_rem);
+            cozk_primary* pr = nullptr;
+            rc_check(cozk_primary_create(env.ctx, c.mode, ps.party, h->instrs.data(), n_instr, flp.data(), Ep.data(), n_mem, outr.h, eqr.h, &pr), env.ctx,
+                     "primary_create(remaining rounds)");
+            PrimaryH prh(pr);
+            PrimaryFinals fin;
+            (void)prove_primary_rounds(env, pstars[0], pr, c.log_workers, n_mem, n_instr, fin);
+            send_primary_openings(env, pstars[0], fin);
+        }
+        env.star = star;
     }
     double t0 = now_ms();
     ps.t_primary = t0 - tp0;
@@ -299,16 +423,16 @@ fe lookups_eval_circuit_major(cozk_lookups* h, const std::vector<const cozk_poly
     return acc;
 }
 
-int lookups_coordinator_main(cozk_lookups* h, StarNetCoordinator& net, LookupsProof& proof, bool verify, std::string& why) {
+int lookups_coordinator_main(cozk_lookups* h, StarNetCoordinator& net, StarNetCoordinator& pnet, LookupsProof& proof, bool verify, std::string& why) {
     Transcript tr("cozk-lookups");
     std::vector<fe> r_eq, r_primary;
     if (h->cfg.primary) {
         r_eq = tr.challenge_vector((size_t)h->cfg.log_n);
         Writer w;
         w.vec_fr(r_eq);
-        net.broadcast_request(w.b);
+        pnet.broadcast_request(w.b);
         proof.has_primary = true;
-        proof.primary = coordinate_primary_sumcheck(net, tr, h->cfg.log_n, r_primary);
+        proof.primary = coordinate_primary_sumcheck(pnet, tr, h->cfg.log_n, r_primary, h->nparties, h->cfg.log_workers);
     }
     size_t num_layers = (size_t)h->cfg.log_n + 1;  // tree_depth sparse layers + the toggle layer
     std::vector<fe> r;
@@ -386,6 +510,7 @@ int cozk_lookups_create(const cozk_lookups_config* cfg, cozk_lookups** out) {
     h->cfg = *cfg;
     try {
         COZK_REQUIRE(cfg->mode == COZK_MODE_PLAIN || cfg->mode == COZK_MODE_REP3, "lookups: mode");
+        COZK_REQUIRE(cfg->log_workers >= 0 && cfg->log_workers <= 3 && cfg->log_workers < cfg->log_n, "lookups: log_workers in 0..3, below log_n");
         COZK_REQUIRE(cfg->log_n >= 1 && cfg->log_n <= 24 && cfg->n_pairs >= 1 && cfg->n_pairs <= 128 && cfg->density_pct >= 0 && cfg->density_pct <= 100,
                      "lookups: log_n in 1..24, n_pairs in 1..128, density_pct in 0..100");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
@@ -454,24 +579,31 @@ int cozk_lookups_prove(cozk_lookups* h, int verify, cozk_lookups_result* res) {
     memset(res, 0, sizeof *res);
     res->verified = -1;
     int np = h->nparties;
+    const int W = 1 << h->cfg.log_workers;
     InProcStar star(np);
+    InProcStar pstar(np * W);  // the primary sumcheck's worker sub-nets: participant = worker * parties + party
+    pstar.abort.flag.store(false);
     InProcRing ring(&star.abort);
-    std::vector<std::unique_ptr<InProcStarWorker>> sw;
+    std::vector<std::unique_ptr<InProcStarWorker>> sw, psw;
     std::vector<std::unique_ptr<InProcRingNet>> rn;
     for (int p = 0; p < np; p++) {
         sw.emplace_back(new InProcStarWorker(&star, p));
         rn.emplace_back(np == 3 ? new InProcRingNet(&ring, p) : nullptr);
         h->parties[p].error.clear();
     }
+    for (int id = 0; id < np * W; id++) psw.emplace_back(new InProcStarWorker(&pstar, id));
     std::vector<std::thread> threads;
     double t0 = now_ms();
     for (int p = 0; p < np; p++) {
         threads.emplace_back([&, p] {
             try {
-                lookups_worker_main(h, h->parties[p], sw[p].get(), rn[p].get());
+                std::vector<StarNetWorker*> mine;
+                for (int w = 0; w < W; w++) mine.push_back(psw[(size_t)w * np + p].get());
+                lookups_worker_main(h, h->parties[p], sw[p].get(), mine, rn[p].get());
             } catch (const std::exception& e) {
                 h->parties[p].error = e.what();
                 star.abort.flag.store(true);
+                pstar.abort.flag.store(true);
             }
         });
     }
@@ -480,11 +612,12 @@ int cozk_lookups_prove(cozk_lookups* h, int verify, cozk_lookups_result* res) {
     int verified = -1;
     int rc = COZK_OK;
     try {
-        InProcStarCoordinator coord(&star);
-        verified = lookups_coordinator_main(h, coord, proof, verify != 0, why);
+        InProcStarCoordinator coord(&star), pcoord(&pstar);
+        verified = lookups_coordinator_main(h, coord, pcoord, proof, verify != 0, why);
     } catch (const std::exception& e) {
         h->error = std::string("coordinator: ") + e.what();
         star.abort.flag.store(true);
+        pstar.abort.flag.store(true);
         rc = COZK_ERR_INTERNAL;
     }
     for (auto& t : threads) t.join();

@@ -681,7 +681,16 @@ static inline std::vector<fe> unipoly_from_evals_general(const std::vector<fe>& 
 // go up, r_j comes down; every multiplication level of the collations is one mul_vec over all items (local half on the
 // device, ring reshare here).  Afterwards the final claims are sent as additive shares in the order E, flags, outputs
 // (the primary_sumcheck_openings of worker.rs:128-141).  Returns the challenges in round order.
-static std::vector<fe> prove_primary_sumcheck_worker(WorkerEnv& env, cozk_primary* prim, int num_rounds, size_t n_mem, size_t n_instr) {
+struct PrimaryFinals {
+    std::vector<Share> E;      // E_m(r) as shares
+    std::vector<fe> flags;     // flag_i(r), public
+    Share outputs;
+    fe eq;
+};
+// the rounds of prove_primary_sumcheck_inner over ONE polynomial set (a whole trace, a worker's chunk, or the 2^k gathered
+// finals): sends the evaluations, receives r_j, returns the challenges and the set's final values
+static std::vector<fe> prove_primary_rounds(WorkerEnv& env, StarNetWorker* star, cozk_primary* prim, int num_rounds, size_t n_mem, size_t n_instr,
+                                            PrimaryFinals& fin) {
     const int D = cozk_primary_degree(prim);
     std::vector<fe> rs;
     uint64_t rr[4];
@@ -705,8 +714,8 @@ static std::vector<fe> prove_primary_sumcheck_worker(WorkerEnv& env, cozk_primar
         for (int k = 0; k < D; k++) msg[k] = fe_from_u64x4(ev.data() + 4 * k);
         Writer w;
         w.vec_fr(msg);
-        env.star->send_response(w.b);
-        Bytes req = env.star->receive_request();
+        star->send_response(w.b);
+        Bytes req = star->receive_request();
         Reader rd(req);
         fe r_j = rd.fr();
         rs.push_back(r_j);
@@ -715,13 +724,28 @@ static std::vector<fe> prove_primary_sumcheck_worker(WorkerEnv& env, cozk_primar
     std::vector<uint64_t> Ee(8 * n_mem), Fe(4 * n_instr);
     uint64_t oe[8], qe[4];
     rc_check(cozk_primary_final_evals(env.ctx, prim, rr, Ee.data(), Fe.data(), oe, qe), env.ctx, "primary_final_evals");
+    fin.E.clear();
+    fin.flags.clear();
+    for (size_t m = 0; m < n_mem; m++) fin.E.push_back(Share{fe_from_u64x4(Ee.data() + 8 * m), fe_from_u64x4(Ee.data() + 8 * m + 4)});
+    for (size_t i = 0; i < n_instr; i++) fin.flags.push_back(fe_from_u64x4(Fe.data() + 4 * i));
+    fin.outputs = Share{fe_from_u64x4(oe), fe_from_u64x4(oe + 4)};
+    fin.eq = fe_from_u64x4(qe);
+    return rs;
+}
+// the final claims as additive shares in the order E, flags, outputs (the primary_sumcheck_openings of worker.rs:128-141)
+static void send_primary_openings(WorkerEnv& env, StarNetWorker* star, const PrimaryFinals& fin) {
     std::vector<fe> openings;
-    for (size_t m = 0; m < n_mem; m++) openings.push_back(env.into_additive(Share{fe_from_u64x4(Ee.data() + 8 * m), fe_from_u64x4(Ee.data() + 8 * m + 4)}));
-    for (size_t i = 0; i < n_instr; i++) openings.push_back(env.mode == COZK_MODE_REP3 ? env.additive_trivial(fe_from_u64x4(Fe.data() + 4 * i)) : fe_from_u64x4(Fe.data() + 4 * i));
-    openings.push_back(env.into_additive(Share{fe_from_u64x4(oe), fe_from_u64x4(oe + 4)}));
+    for (const Share& e : fin.E) openings.push_back(env.into_additive(e));
+    for (const fe& f : fin.flags) openings.push_back(env.mode == COZK_MODE_REP3 ? env.additive_trivial(f) : f);
+    openings.push_back(env.into_additive(fin.outputs));
     Writer w;
     w.vec_fr(openings);
-    env.star->send_response(w.b);
+    star->send_response(w.b);
+}
+static std::vector<fe> prove_primary_sumcheck_worker(WorkerEnv& env, cozk_primary* prim, int num_rounds, size_t n_mem, size_t n_instr) {
+    PrimaryFinals fin;
+    std::vector<fe> rs = prove_primary_rounds(env, env.star, prim, num_rounds, n_mem, n_instr, fin);
+    send_primary_openings(env, env.star, fin);
     return rs;
 }
 
@@ -730,18 +754,28 @@ struct PrimarySumcheckProof {
     std::vector<fe> openings;  // E(r) (n_mem), flags(r) (n_instr), lookup_outputs(r)
 };
 
-// prove_primary_sumcheck_rep3 (jolt/vm/instruction_lookups/coordinator.rs:97-150) + the final claims
-static PrimarySumcheckProof coordinate_primary_sumcheck(StarNetCoordinator& net, Transcript& tr, int num_rounds, std::vector<fe>& r_out) {
+// prove_primary_sumcheck_rep3 (jolt/vm/instruction_lookups/coordinator.rs:97-150) + the final claims.  n_participants = parties x
+// workers (participant id = worker * parties + party); during the first num_rounds - log_workers rounds every worker
+// sub-net responds and the coordinator adds all of them (:112-128), afterwards only worker 0 of every party does (:107-111)
+static PrimarySumcheckProof coordinate_primary_sumcheck(StarNetCoordinator& net, Transcript& tr, int num_rounds, std::vector<fe>& r_out, int nparties = 0,
+                                                        int log_workers = 0) {
     PrimarySumcheckProof proof;
     fe previous_claim = Fr::zero();
     r_out.clear();
-    for (int round = 0; round < num_rounds; round++) {
+    if (nparties <= 0) nparties = net.n_workers();
+    const int all = net.n_workers();
+    auto gather = [&](int count) {
         std::vector<std::vector<fe>> parts;
-        for (Bytes& b : net.receive_responses()) {
+        for (int id = 0; id < count; id++) {
+            Bytes b = net.receive_response(id);
             Reader rd(b);
             parts.push_back(rd.vec_fr());
         }
-        std::vector<fe> ev = combine_additive(parts);
+        return combine_additive(parts);
+    };
+    for (int round = 0; round < num_rounds; round++) {
+        const bool split_round = round < num_rounds - log_workers;
+        std::vector<fe> ev = gather(split_round ? all : nparties);
         ev.insert(ev.begin() + 1, Fr::sub(previous_claim, ev[0]));  // round_evals.insert(1, previous_claim - round_evals[0])
         std::vector<fe> poly = unipoly_from_evals_general(ev);
         std::vector<fe> comp = unipoly_compress(poly);
@@ -750,16 +784,11 @@ static PrimarySumcheckProof coordinate_primary_sumcheck(StarNetCoordinator& net,
         fe r_j = tr.challenge_scalar();
         Writer w;
         w.fr(r_j);
-        net.broadcast_request(w.b);
+        for (int id = 0; id < (split_round ? all : nparties); id++) net.send_request(id, w.b);
         r_out.push_back(r_j);
         previous_claim = unipoly_eval(poly, r_j);
     }
-    std::vector<std::vector<fe>> parts;
-    for (Bytes& b : net.receive_responses()) {
-        Reader rd(b);
-        parts.push_back(rd.vec_fr());
-    }
-    proof.openings = combine_additive(parts);
+    proof.openings = gather(nparties);
     tr.append_scalars(proof.openings);
     return proof;
 }

@@ -12,7 +12,7 @@ from .engine import Vec, fr_to_mont_limbs, mont_limbs_to_int
 
 class LookupsConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("n_pairs", ctypes.c_int), ("density_pct", ctypes.c_int),
-                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64), ("primary", ctypes.c_int)]
+                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64), ("log_workers", ctypes.c_int), ("primary", ctypes.c_int)]
 
 
 class LookupsResult(ctypes.Structure):
@@ -64,7 +64,7 @@ def _decl():
 
 
 class LookupsHarness:
-    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1, primary=False):
+    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1, primary=False, log_workers=0):
         self._l = _decl()
         cfg = LookupsConfig()
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
@@ -72,6 +72,7 @@ class LookupsHarness:
         cfg.devices = (ctypes.c_int * 3)(*devices)
         cfg.seed = seed
         cfg.primary = 1 if primary else 0
+        cfg.log_workers = log_workers
         h = _vp()
         rc = self._l.cozk_lookups_create(ctypes.byref(cfg), ctypes.byref(h))
         self.h = h

@@ -348,6 +348,7 @@ typedef struct cozk_primary_instr {
     int mems[8]; /* indices into the E polynomials */
     int bits;    /* CONCAT: operand bits per chunk */
 } cozk_primary_instr;
+/* flags: U8 0/1 columns, or FR vectors (flags that are already bound: the remaining rounds after a worker sub-net split) */
 int cozk_primary_create(cozk_ctx* ctx, int mode, int party_id, const cozk_primary_instr* instrs, size_t n_instr,
                         const cozk_vec* const* flags, const cozk_poly* const* E, size_t n_mem,
                         const cozk_poly* lookup_outputs, const cozk_vec* eq, cozk_primary** out);
@@ -645,6 +646,10 @@ typedef struct cozk_lookups_config {
     int density_pct; /* share of the flags that are set, 0..100 */
     int devices[3];
     uint64_t seed;
+    int log_workers; /* worker sub-nets of the primary sumcheck (jolt/vm/instruction_lookups/worker.rs:194-360, coordinator.rs:
+                        97-150): 2^log_workers workers per party, each proving the first log_n - log_workers rounds on its
+                        high-variable chunk of every polynomial; worker 0 finishes the rest on the gathered finals.  The
+                        workers of a party are time-sliced on its context here (one GPU each in a real deployment) */
     int primary; /* 1: run Lasso's primary sumcheck first (n_pairs E polynomials, a five-instruction synthetic table of the
                     three collation forms, lookup_outputs = sum_i flag_i g_i(E)); the proof then starts with its part */
 } cozk_lookups_config;

@@ -157,3 +157,32 @@ def test_primary_sumcheck_2p14_verifies_and_rep3_equals_plain(cozk):
         digs[mode] = bytes(r.proof_digest)
         h.close()
     assert digs["plain"] == digs["rep3"]
+
+
+@pytest.mark.parametrize("mode", ["plain", "rep3"])
+@pytest.mark.parametrize("logw", [1, 2])
+def test_primary_sumcheck_worker_subnets_give_the_same_proof(cozk, mode, logw):
+    """the worker sub-net split of the primary sumcheck (jolt/vm/instruction_lookups/worker.rs:194-372, coordinator.rs:97-150):
+    every worker proves the first log_n - log_workers rounds on its high-variable chunk (the coordinator adds the sub-nets'
+    evaluations), worker 0 finishes on the 2^log_workers gathered finals; the proof is byte-identical to the unsplit one
+    and to the oracle's"""
+    LK = importlib.import_module("co-zkvms_amd.lookups")
+    cfg = dict(log_n=6, n_pairs=19, density_pct=30, seed=21)
+    h = LK.LookupsHarness(mode=mode, primary=True, log_workers=logw, **cfg)
+    res = h.prove(verify=True)
+    assert res.verified == 1, h.last_error()
+    ref = pylookups.run(dict(cfg, mode=mode, primary=1))
+    assert h.proof_bytes(res) == ref["proof_bytes"]
+    h.close()
+
+
+def test_primary_sumcheck_split_2p14_equals_unsplit(cozk):
+    LK = importlib.import_module("co-zkvms_amd.lookups")
+    digs = []
+    for logw in (0, 3):
+        h = LK.LookupsHarness(mode="rep3", log_n=14, n_pairs=54, density_pct=10, seed=2026, primary=True, log_workers=logw)
+        r = h.prove(verify=True)
+        assert r.verified == 1, h.last_error()
+        digs.append(bytes(r.proof_digest))
+        h.close()
+    assert digs[0] == digs[1]
