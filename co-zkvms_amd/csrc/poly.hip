@@ -317,7 +317,7 @@ __global__ void __launch_bounds__(PT) k_layer_cubic(const fe* __restrict__ a, co
         fe e[3];
         fe scale;
         if (NESTED) {
-            size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+            size_t x2 = c >> (__ffsll((long long)E1_half) - 1), x1 = c & (E1_half - 1);  // E1_half is a power of two
             eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
             scale = fe_load(E2 + x2);
         } else {
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic(const fe* __restrict__ 
             fe e[3];
             fe scale;
             if (NESTED) {
-                size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+                size_t x2 = c >> (__ffsll((long long)E1_half) - 1), x1 = c & (E1_half - 1);  // E1_half is a power of two
                 eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
                 scale = fe_load(E2 + x2);
             } else {
@@ -452,7 +452,7 @@ __global__ void __launch_bounds__(RT) k_layer_round_small(const fe* __restrict__
         fe e[3];
         fe scale = Fr::zero();
         if (nested) {
-            size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+            size_t x2 = c >> (__ffsll((long long)E1_half) - 1), x1 = c & (E1_half - 1);  // E1_half is a power of two
             eq3(fe_load(E1 + 2 * x1), fe_load(E1 + 2 * x1 + 1), e);
             scale = fe_load(E2 + x2);
         } else {
@@ -643,7 +643,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
             for (size_t c = threadIdx.x - 320 * pt; c < nch; c += 320) {
                 fe e0, e1v, ek;
                 if (nested) {
-                    size_t x2 = c / E1_half, x1 = c - x2 * E1_half;
+                    size_t x2 = c >> (__ffsll((long long)E1_half) - 1), x1 = c & (E1_half - 1);  // E1_half is a power of two
                     e0 = fe_load(E1 + 2 * x1);
                     e1v = fe_load(E1 + 2 * x1 + 1);
                 } else {
@@ -668,7 +668,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
                 }
                 fe lr = sh_local_mul<NC>(lk, rk);
                 // same association as k_layer_cubic ((l x r) e) scale: field products are exact, any order agrees
-                fe es = nested ? Fr::mul(ek, fe_load(E2 + c / E1_half)) : ek;
+                fe es = nested ? Fr::mul(ek, fe_load(E2 + (c >> (__ffsll((long long)E1_half) - 1)))) : ek;
                 acc = Fr::add(acc, Fr::mul(lr, es));
             }
         }
