@@ -94,6 +94,12 @@ __global__ void __launch_bounds__(256) k_bench_montmul(fe* x, int iters) {
         f9 x9 = f9_from_fe(a), y9 = f9_from_fe(b);
         for (int k = 0; k < iters; k++) x9 = f9_mul(x9, y9);
         a = f9_to_fe(x9);
+    } else if (VARIANT == 3) {
+        // two 9 x 29 products with interleaved accumulator chains
+        f9 x9 = f9_from_fe(a), y9 = f9_from_fe(b), z9 = y9;
+        z9.l[1] ^= 0x155u;
+        for (int k = 0; k < iters; k += 2) f9_mul_x2(x9, y9, z9, y9, x9, z9);
+        a = Fq::add(f9_to_fe(x9), f9_to_fe(z9));
     } else {
         // two independent chains (ILP probe)
         fe c = b;
@@ -386,9 +392,14 @@ int cozk_bench_montmul(cozk_ctx* ctx, size_t lanes, int iters, int variant, doub
         HIP_TRY(hipEventCreate(&e1));
         // warm-up launch, then the timed one
         auto launch = [&](int it) {
-            if (variant == 0) k_bench_montmul<0><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, it);
-            else if (variant == 2) k_bench_montmul<2><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, it);
-            else k_bench_montmul<1><<<(unsigned)(lanes / 256), 256, 0, ctx->stream>>>(x, it);
+            // bits 8.. of `variant`: KiB of dynamic LDS per workgroup, an occupancy limiter for the probe (160 KiB per CU,
+            // one wave per SIMD per workgroup: 40 KiB -> 4 waves per SIMD, 53 -> 3, 64 -> 2)
+            const int v = variant & 0xff;
+            const size_t lds = (size_t)(variant >> 8) * 1024;
+            if (v == 0) k_bench_montmul<0><<<(unsigned)(lanes / 256), 256, lds, ctx->stream>>>(x, it);
+            else if (v == 2) k_bench_montmul<2><<<(unsigned)(lanes / 256), 256, lds, ctx->stream>>>(x, it);
+            else if (v == 3) k_bench_montmul<3><<<(unsigned)(lanes / 256), 256, lds, ctx->stream>>>(x, it);
+            else k_bench_montmul<1><<<(unsigned)(lanes / 256), 256, lds, ctx->stream>>>(x, it);
         };
         launch(8);
         HIP_TRY(hipEventRecord(e0, ctx->stream));

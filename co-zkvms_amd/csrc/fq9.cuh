@@ -76,6 +76,23 @@ static __device__ __forceinline__ f9 f9_mul(const f9& a, const f9& b) {
     F9_MUL_BODY
     return r;
 }
+// two independent products with their accumulator chains interleaved instruction by instruction: a single chain is one
+// long run of dependent v_mad_u64_u32, which needs other waves of the SIMD to cover the multiplier's latency
+static __device__ __forceinline__ void f9_mul_x2(const f9& a, const f9& b, const f9& a2, const f9& b2, f9& r, f9& r2) {
+    uint64_t acc = 0, acc2 = 0;
+    uint32_t m[9], m2[9];
+    F9_MUL_X2_BODY
+}
+static __device__ __forceinline__ void f9_sqr_x2(const f9& a, const f9& a2, f9& r, f9& r2) {
+    uint64_t acc = 0, acc2 = 0;
+    uint32_t m[9], m2[9], dd[9], dd2[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        dd[i] = a.l[i] << 1;
+        dd2[i] = a2.l[i] << 1;
+    }
+    F9_SQR_X2_BODY
+}
 // a * a / R' mod p for a normalised a: the 36 off-diagonal products are taken once against the doubled operand
 // (limbs < 2^30, products < 2^59, at most 4 of them + one square + 9 m*p terms per column: < 2^62)
 static __device__ __forceinline__ f9 f9_sqr(const f9& a) {

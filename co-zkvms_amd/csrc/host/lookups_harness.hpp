@@ -52,19 +52,55 @@ std::vector<uint8_t> lookups_flag_column(const cozk_lookups_config& c, int q, si
     return col;
 }
 
-// the synthetic instruction table of the primary sumcheck: three CONCAT (AND / OR / XOR-like), one PRODUCT (BEQ-like) and
-// one LTU (SLTU-like) instruction with C = 4 chunks over memory indices taken modulo n_mem
+// the instruction table of the primary sumcheck: the 27 RV32I instructions in the order of jolt/vm/rv32i_vm.rs:41-70, each
+// with the collation form and memory count of its combine_lookups at C = 4, M = 2^16 (co-jolt/src/jolt/instruction/*.rs).
+// WHICH memory an instruction's subtable lands in comes from jolt-core's preprocessing (out of tree): the harness
+// assigns them synthetically, instruction t using memories 3 t, 3 t + 1, .. modulo n_mem (instructions share memories,
+// as they share subtables in the VM).
 std::vector<cozk_primary_instr> lookups_instr_table(int n_mem) {
-    auto mk = [&](int form, std::initializer_list<int> mems, int bits) {
-        cozk_primary_instr in{};
-        in.form = form;
-        in.bits = bits;
-        in.n_mems = 0;
-        for (int m : mems) in.mems[in.n_mems++] = m % n_mem;
-        return in;
+    struct Row {
+        int form, n_mems, bits, repeat;
     };
-    return {mk(COZK_G_CONCAT, {0, 1, 2, 3}, 8), mk(COZK_G_CONCAT, {4, 5, 6, 7}, 8), mk(COZK_G_CONCAT, {4, 1, 6, 3}, 4), mk(COZK_G_PRODUCT, {8, 9, 10, 11}, 0),
-            mk(COZK_G_LTU, {12, 13, 14, 15, 16, 17, 18}, 0)};
+    const int C = 4;
+    static const Row rows[27] = {
+        {COZK_G_CONCAT, C / 2, 16, 0},              // ADD   add.rs:29-33
+        {COZK_G_CONCAT, C / 2, 16, 0},              // SUB   sub.rs:31-36
+        {COZK_G_CONCAT, C, 8, 0},                   // AND   and.rs:34-36
+        {COZK_G_CONCAT, C, 8, 0},                   // OR
+        {COZK_G_CONCAT, C, 8, 0},                   // XOR
+        {COZK_G_PRODUCT, C, 0, 0},                  // BEQ   beq.rs:35-37
+        {COZK_G_NOT_SLT, 2 * C + 1, 0, 0},          // BGE   bge.rs:34-43
+        {COZK_G_NOT_LTU, 2 * C - 1, 0, 0},          // BGEU
+        {COZK_G_NOT_PRODUCT, C, 0, 0},              // BNE
+        {COZK_G_SLT, 2 * C + 1, 0, 0},              // SLT   slt.rs:33-59
+        {COZK_G_LTU, 2 * C - 1, 0, 0},              // SLTU  sltu.rs:32-47
+        {COZK_G_CONCAT, C, 8, 0},                   // SLL   sll.rs:32-35
+        {COZK_G_CONCAT, C + 1, 0, 0},               // SRA   sra.rs:32-36 (sum)
+        {COZK_G_CONCAT, C, 0, 0},                   // SRL   srl.rs (sum)
+        {COZK_G_CONCAT, 2, 16, 1},                  // MOVSIGN  virtual_movsign.rs:36-42: the one value repeated WORD_SIZE / 16 times
+        {COZK_G_CONCAT, C / 2, 16, 0},              // MUL
+        {COZK_G_CONCAT, C / 2, 16, 0},              // MULU
+        {COZK_G_CONCAT, C / 2, 16, 0},              // MULHU
+        {COZK_G_CONCAT, C / 2, 16, 0},              // VIRTUAL_ADVICE
+        {COZK_G_CONCAT, C, 16, 0},                  // VIRTUAL_MOVE  virtual_move.rs:26-28
+        {COZK_G_LTE, 2 * C, 0, 0},                  // VIRTUAL_ASSERT_LTE
+        {COZK_G_SIGNED_REM, 4 * C + 2, 0, 0},       // VIRTUAL_ASSERT_VALID_SIGNED_REMAINDER
+        {COZK_G_UNSIGNED_REM, 3 * C - 1, 0, 0},     // VIRTUAL_ASSERT_VALID_UNSIGNED_REMAINDER
+        {COZK_G_DIV0, 2 * C, 0, 0},                 // VIRTUAL_ASSERT_VALID_DIV0
+        {COZK_G_NOT_FIRST, 1, 0, 0},                // VIRTUAL_ASSERT_HALFWORD_ALIGNMENT
+        {COZK_G_ZERO, 1, 0, 0},                     // VIRTUAL_POW2
+        {COZK_G_ZERO, 1, 0, 0},                     // VIRTUAL_SRA_PADDING
+    };
+    std::vector<cozk_primary_instr> out;
+    for (int t = 0; t < 27; t++) {
+        cozk_primary_instr in{};
+        in.form = rows[t].form;
+        in.bits = rows[t].bits;
+        in.n_mems = rows[t].n_mems;
+        for (int j = 0; j < in.n_mems; j++) in.mems[j] = (3 * t + (rows[t].repeat ? 0 : j)) % n_mem;
+        out.push_back(in);
+    }
+    return out;
 }
 
 // the dealer's view: which instruction every cycle runs and lookup_outputs(x) = g_{which(x)}(E(x)) in the clear
@@ -295,7 +331,7 @@ void lookups_worker_main(cozk_lookups* h, LookupsParty& ps, StarNetWorker* star,
                         void* recv = nullptr;
                         size_t n = 0;
                         rc_check(cozk_primary_level(env.ctx, prims[w].h, level, env.key_self, env.key_prev, env.mask_ctr, &send, &recv, &n), env.ctx, "primary_level");
-                        if (env.mode == COZK_MODE_REP3) {
+                        if (env.mode == COZK_MODE_REP3 && n) {
                             env.ring->reshare(env.ctx, (const fe*)send, (fe*)recv, n);
                             env.mask_ctr += n;
                         }
@@ -441,7 +477,7 @@ int lookups_coordinator_main(cozk_lookups* h, StarNetCoordinator& net, StarNetCo
     Transcript vt("cozk-lookups");
     if (h->cfg.primary) {
         std::vector<fe> vr_eq = vt.challenge_vector((size_t)h->cfg.log_n), rs;
-        const int degree = 6;  // max g degree (C = 4) + 2
+        const int degree = primary_sumcheck_degree(h->instrs);
         if (!verify_primary_sumcheck(proof.primary, h->instrs, (size_t)h->cfg.n_pairs, degree, vr_eq, vt, rs)) {
             why = "primary sumcheck: a round or the final claim does not hold";
             return 0;

@@ -703,7 +703,7 @@ static std::vector<fe> prove_primary_rounds(WorkerEnv& env, StarNetWorker* star,
             void* recv = nullptr;
             size_t n = 0;
             rc_check(cozk_primary_level(env.ctx, prim, level, env.key_self, env.key_prev, env.mask_ctr, &send, &recv, &n), env.ctx, "primary_level");
-            if (env.mode == COZK_MODE_REP3) {
+            if (env.mode == COZK_MODE_REP3 && n) {  // n == 0: no active instruction has a value to reshare at this level (public knowledge)
                 env.ring->reshare(env.ctx, (const fe*)send, (fe*)recv, n);
                 env.mask_ctr += n;
             }
@@ -793,30 +793,108 @@ static PrimarySumcheckProof coordinate_primary_sumcheck(StarNetCoordinator& net,
     return proof;
 }
 
-// g_i on opened values (the verifier's side of combine_lookups)
+// g_i on opened values (the verifier's side: the PLAIN combine_lookups of co-jolt/src/jolt/instruction/*.rs, written from the
+// formulas there and independently of the device's collation programs)
 static inline fe primary_g_plain(const cozk_primary_instr& in, const std::vector<fe>& E) {
-    if (in.form == COZK_G_CONCAT) {
-        fe shift = Fr::one(), two = Fr::from_u64(2);
-        for (int b = 0; b < in.bits; b++) shift = Fr::mul(shift, two);
-        fe acc = Fr::zero(), w = Fr::one();
-        for (int t = in.n_mems - 1; t >= 0; t--) {
-            acc = Fr::add(acc, Fr::mul(E[in.mems[t]], w));
-            w = Fr::mul(w, shift);
+    const fe one = Fr::one();
+    const int n = in.n_mems;
+    auto v = [&](int pos) { return E[in.mems[pos]]; };
+    auto prod = [&](int p0, int cnt) {
+        fe acc = one;
+        for (int t = 0; t < cnt; t++) acc = Fr::mul(acc, v(p0 + t));
+        return acc;
+    };
+    // sum_{i < C} ltu_i prod_{j < i} eq_j; *eq_prod = prod_{j < n_eq} eq_j  (sltu.rs:32-47, virtual_assert_lte.rs:33-50)
+    auto ltu_sum = [&](int C, int l0, int e0, int n_eq, fe* eq_prod) {
+        fe s = Fr::zero(), pr = one;
+        for (int i = 0; i < C; i++) {
+            s = Fr::add(s, Fr::mul(v(l0 + i), pr));
+            if (i < n_eq) pr = Fr::mul(pr, v(e0 + i));
         }
-        return acc;
+        if (eq_prod) *eq_prod = pr;
+        return s;
+    };
+    switch (in.form) {
+        case COZK_G_CONCAT: {  // utils/instruction_utils.rs concatenate_lookups
+            fe shift = one, two = Fr::from_u64(2);
+            for (int b = 0; b < in.bits; b++) shift = Fr::mul(shift, two);
+            fe acc = Fr::zero(), w = one;
+            for (int t = n - 1; t >= 0; t--) {
+                acc = Fr::add(acc, Fr::mul(v(t), w));
+                w = Fr::mul(w, shift);
+            }
+            return acc;
+        }
+        case COZK_G_PRODUCT: return prod(0, n);                      // beq.rs:35-37
+        case COZK_G_NOT_PRODUCT: return Fr::sub(one, prod(0, n));    // bne.rs:33-35
+        case COZK_G_LTU: return ltu_sum((n + 1) / 2, 0, (n + 1) / 2, (n + 1) / 2 - 1, nullptr);
+        case COZK_G_NOT_LTU: return Fr::sub(one, ltu_sum((n + 1) / 2, 0, (n + 1) / 2, (n + 1) / 2 - 1, nullptr));  // bgeu.rs:31-39
+        case COZK_G_SLT:
+        case COZK_G_NOT_SLT: {  // slt.rs:33-59
+            const int C = (n - 1) / 2;
+            const fe l = v(0), r = v(1), lt_abs = v(2 * C - 1), eq_abs = v(2 * C);
+            fe s = lt_abs, pr = eq_abs;
+            for (int i = 0; i <= C - 2; i++) {
+                s = Fr::add(s, Fr::mul(v(2 + i), pr));
+                if (i < C - 2) pr = Fr::mul(pr, v(C + 1 + i));
+            }
+            fe eq_s = Fr::add(Fr::mul(l, r), Fr::mul(Fr::sub(one, l), Fr::sub(one, r)));
+            fe g = Fr::add(Fr::mul(l, Fr::sub(one, r)), Fr::mul(eq_s, s));
+            return in.form == COZK_G_SLT ? g : Fr::sub(one, g);  // bge.rs:34-43
+        }
+        case COZK_G_LTE: {  // virtual_assert_lte.rs:33-50
+            fe pr;
+            fe s = ltu_sum(n / 2, 0, n / 2, n / 2, &pr);
+            return Fr::add(s, pr);
+        }
+        case COZK_G_NOT_FIRST: return Fr::sub(one, v(0));  // virtual_assert_halfword_alignment.rs:33-37
+        case COZK_G_DIV0: return Fr::add(Fr::sub(one, prod(0, n / 2)), prod(n / 2, n / 2));  // virtual_assert_valid_div0.rs:36-42
+        case COZK_G_UNSIGNED_REM: {  // virtual_assert_valid_unsigned_remainder.rs:30-45
+            const int C = (n + 1) / 3;
+            return Fr::add(ltu_sum(C, 0, C, C - 1, nullptr), prod(2 * C - 1, C));
+        }
+        case COZK_G_SIGNED_REM: {  // virtual_assert_valid_signed_remainder.rs:40-67
+            const int C = (n - 2) / 4;
+            const fe l = v(0), r = v(1);
+            fe s = v(2 * C + 1), pr = v(2 * C);  // lt_abs, eq_abs
+            for (int i = 0; i <= C - 2; i++) {
+                s = Fr::add(s, Fr::mul(v(C + 1 + i), pr));
+                pr = Fr::mul(pr, v(2 + i));
+            }
+            fe rem_zero = prod(2 * C + 2, C), div_zero = prod(3 * C + 2, C);
+            fe g = Fr::mul(Fr::sub(Fr::sub(one, l), r), s);
+            g = Fr::add(g, Fr::mul(Fr::mul(l, r), Fr::sub(one, pr)));
+            g = Fr::add(g, Fr::mul(Fr::mul(Fr::sub(one, l), r), rem_zero));
+            return Fr::add(g, div_zero);
+        }
+        default: return Fr::zero();  // COZK_G_ZERO: virtual_pow2.rs:20-22
     }
-    if (in.form == COZK_G_PRODUCT) {
-        fe acc = Fr::one();
-        for (int t = 0; t < in.n_mems; t++) acc = Fr::mul(acc, E[in.mems[t]]);
-        return acc;
+}
+
+// g_poly_degree of a form (co-jolt/src/jolt/instruction/*.rs; SLT / BGE: C + 2, the true degree -- slt.rs:61-63 says C + 1,
+// which the RV32I set's maximum C + 2 of the signed remainder covers) and sumcheck_poly_degree (worker.rs:701-708)
+static inline int primary_g_degree(const cozk_primary_instr& in) {
+    const int n = in.n_mems;
+    switch (in.form) {
+        case COZK_G_CONCAT:
+        case COZK_G_NOT_FIRST:
+        case COZK_G_ZERO: return 1;
+        case COZK_G_PRODUCT:
+        case COZK_G_NOT_PRODUCT: return n;
+        case COZK_G_LTU:
+        case COZK_G_NOT_LTU: return (n + 1) / 2;
+        case COZK_G_LTE:
+        case COZK_G_DIV0: return n / 2;
+        case COZK_G_UNSIGNED_REM: return (n + 1) / 3;
+        case COZK_G_SLT:
+        case COZK_G_NOT_SLT: return (n - 1) / 2 + 2;
+        default: return (n - 2) / 4 + 2;  // COZK_G_SIGNED_REM
     }
-    int C = (in.n_mems + 1) / 2;
-    fe s = Fr::zero(), prod = Fr::one();
-    for (int i = 0; i < C; i++) {
-        s = Fr::add(s, Fr::mul(E[in.mems[i]], prod));
-        if (i < C - 1) prod = Fr::mul(prod, E[in.mems[C + i]]);
-    }
-    return s;
+}
+static inline int primary_sumcheck_degree(const std::vector<cozk_primary_instr>& instrs) {
+    int g = 1;
+    for (const auto& in : instrs) g = std::max(g, primary_g_degree(in));
+    return g + 2;  // eq and flag
 }
 
 // plain verifier of the primary sumcheck (jolt-core verify_primary_sumcheck, out of tree): replay, then

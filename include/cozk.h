@@ -333,20 +333,48 @@ int cozk_toggle_download(cozk_ctx* ctx, const cozk_toggle* t, uint64_t* flags, u
  * (shared) and binds them LowToHigh once per round.  The collations g_i (combine_lookups_rep3_batched,
  * co-jolt/src/jolt/instruction/*.rs) are given as a table of forms over memory indices:
  *   COZK_G_CONCAT  (and.rs:89-101, utils/instruction_utils.rs:26-47): sum_j 2^(bits (n-1-j)) E_mems[j]        -- local
+ *                  ADD SUB AND OR XOR SLL MUL MULU MULHU VIRTUAL_ADVICE VIRTUAL_MOVE; bits = 0: the plain sum of SRA / SRL
+ *                  (sra.rs:122-132); the same memory listed twice: MOVSIGN (virtual_movsign.rs:126-139)
  *   COZK_G_PRODUCT (beq.rs:106-130 -> product_many, mpc-core rep3/arithmetic.rs:86-102): prod_j E_mems[j]
  *   COZK_G_LTU     (sltu.rs:139-170): mems = C LTU memories then C - 1 EQ memories: sum_i ltu_i prod_{j<i} eq_j
- * The last two multiply shared values: each level is ONE batched mul_vec over all active (index, instruction, point)
- * items -- cozk_primary_level does the local half and names the device buffers of the ring exchange, which the host
- * runs (cozk_reshare / its own transport) before the next call. */
+ *   COZK_G_NOT_PRODUCT (bne.rs:108-140), COZK_G_NOT_LTU (bgeu.rs:113-132), COZK_G_NOT_SLT (bge.rs:121-140): 1 - the form
+ *   COZK_G_SLT     (slt.rs:184-302): mems = left_msb, right_msb, C - 1 LTU, C - 2 EQ, lt_abs, eq_abs (2C + 1):
+ *                  l (1 - r) + (l r + (1 - l)(1 - r)) (lt_abs + sum_i ltu_i eq_abs prod_{j<i} eq_j)
+ *   COZK_G_LTE     (virtual_assert_lte.rs:144-209): mems = C LTU then C EQ: sum_i ltu_i prod_{j<i} eq_j + prod_j eq_j
+ *   COZK_G_NOT_FIRST (virtual_assert_halfword_alignment.rs:111-125): 1 - E_mems[0]                               -- local
+ *   COZK_G_DIV0    (virtual_assert_valid_div0.rs:36-42, the plain formula): mems = C left_is_zero then C div_by_zero:
+ *                  1 - prod left_is_zero + prod div_by_zero   (the Rep3 body at :159-225 computes 1 - (.. + ..): a sign
+ *                  slip in the reference that its own plain verifier would reject; not reproduced)
+ *   COZK_G_UNSIGNED_REM (virtual_assert_valid_unsigned_remainder.rs:154-249): mems = C LTU, C - 1 EQ, C right_is_zero:
+ *                  LTU form + prod right_is_zero
+ *   COZK_G_SIGNED_REM (virtual_assert_valid_signed_remainder.rs:40-67; its Rep3 body, :265-273, is todo!() in the reference, the
+ *                  multiplication schedule here is ours): mems = left_msb, right_msb, C - 1 EQ, C - 1 LTU, eq_abs, lt_abs,
+ *                  C left_is_zero, C right_is_zero (4C + 2)
+ *   COZK_G_ZERO    (virtual_pow2.rs:70-78, virtual_right_shift_padding.rs:74-82): 0                                   -- local
+ * The multiplicative forms multiply shared values: each level is ONE batched mul_vec / reshare_additive_many over all
+ * active (index, instruction, point) items -- cozk_primary_level does the local half and names the device buffers of the
+ * ring exchange, which the host runs (cozk_reshare / its own transport) before the next call.  The last multiplication of
+ * every form stays additive (into_additive follows it in worker.rs:553): same totals, one ring round less. */
 #define COZK_G_CONCAT 0
 #define COZK_G_PRODUCT 1
 #define COZK_G_LTU 2
+#define COZK_G_NOT_PRODUCT 3
+#define COZK_G_NOT_LTU 4
+#define COZK_G_SLT 5
+#define COZK_G_NOT_SLT 6
+#define COZK_G_LTE 7
+#define COZK_G_NOT_FIRST 8
+#define COZK_G_DIV0 9
+#define COZK_G_UNSIGNED_REM 10
+#define COZK_G_SIGNED_REM 11
+#define COZK_G_ZERO 12
+#define COZK_PRIMARY_MAX_MEMS 20
 typedef struct cozk_primary cozk_primary;
 typedef struct cozk_primary_instr {
-    int form;    /* COZK_G_* */
-    int n_mems;  /* 1..8 */
-    int mems[8]; /* indices into the E polynomials */
-    int bits;    /* CONCAT: operand bits per chunk */
+    int form;                         /* COZK_G_* */
+    int n_mems;                       /* 1..COZK_PRIMARY_MAX_MEMS (the chunk count C follows from form and n_mems) */
+    int mems[COZK_PRIMARY_MAX_MEMS];  /* indices into the E polynomials, in the order the form lists them */
+    int bits;                         /* CONCAT: operand bits per chunk */
 } cozk_primary_instr;
 /* flags: U8 0/1 columns, or FR vectors (flags that are already bound: the remaining rounds after a worker sub-net split) */
 int cozk_primary_create(cozk_ctx* ctx, int mode, int party_id, const cozk_primary_instr* instrs, size_t n_instr,
@@ -359,7 +387,7 @@ size_t cozk_primary_len(const cozk_primary* p);
  * round_begin: bind with the previous challenge r (NULL in the first round), the pass over the linear instructions, the
  *   item list of the multiplicative ones (*n_items; *n_levels mul_vec levels follow, 0 if there are no items);
  * level (1 .. n_levels): local products + zero-sharing masks PRF(key_self, counter + j) - PRF(key_prev, counter + j) of
- *   n_elems = n_items x degree elements; Rep3: exchange *send -> next party, previous party's -> *recv, then go on;
+ *   n_elems elements (every item's reshared values of this level x degree; 0: nothing to exchange at this level); Rep3: exchange *send -> next party, previous party's -> *recv, then go on;
  * round_finish: out_evals = degree x 4 u64, this party's additive evaluations at X = 0, 2, 3, .., degree. */
 int cozk_primary_round_begin(cozk_ctx* ctx, cozk_primary* p, const uint64_t* r, size_t* n_items, int* n_levels);
 int cozk_primary_level(cozk_ctx* ctx, cozk_primary* p, int level, const uint8_t* key_self, const uint8_t* key_prev,

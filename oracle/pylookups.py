@@ -34,10 +34,16 @@ def serialize(proof):
 
 
 def instr_table(n_mem):
-    """lookups_harness.hpp lookups_instr_table: three CONCAT, one PRODUCT, one LTU instruction, memory indices mod n_mem"""
-    M = lambda xs: [x % n_mem for x in xs]
-    return [P.Instr(P.CONCAT, M([0, 1, 2, 3]), 8), P.Instr(P.CONCAT, M([4, 5, 6, 7]), 8), P.Instr(P.CONCAT, M([4, 1, 6, 3]), 4),
-            P.Instr(P.PRODUCT, M([8, 9, 10, 11])), P.Instr(P.LTU, M([12, 13, 14, 15, 16, 17, 18]))]
+    """lookups_harness.hpp lookups_instr_table: the 27 RV32I instructions (jolt/vm/rv32i_vm.rs:41-70) with the collation form and
+    memory count of their combine_lookups at C = 4, M = 2^16; instruction t uses memories 3 t, 3 t + 1, .. modulo n_mem"""
+    C = 4
+    rows = [(P.CONCAT, C // 2, 16, 0), (P.CONCAT, C // 2, 16, 0), (P.CONCAT, C, 8, 0), (P.CONCAT, C, 8, 0), (P.CONCAT, C, 8, 0),
+            (P.PRODUCT, C, 0, 0), (P.NOT_SLT, 2 * C + 1, 0, 0), (P.NOT_LTU, 2 * C - 1, 0, 0), (P.NOT_PRODUCT, C, 0, 0),
+            (P.SLT, 2 * C + 1, 0, 0), (P.LTU, 2 * C - 1, 0, 0), (P.CONCAT, C, 8, 0), (P.CONCAT, C + 1, 0, 0), (P.CONCAT, C, 0, 0),
+            (P.CONCAT, 2, 16, 1), (P.CONCAT, C // 2, 16, 0), (P.CONCAT, C // 2, 16, 0), (P.CONCAT, C // 2, 16, 0),
+            (P.CONCAT, C // 2, 16, 0), (P.CONCAT, C, 16, 0), (P.LTE, 2 * C, 0, 0), (P.SIGNED_REM, 4 * C + 2, 0, 0),
+            (P.UNSIGNED_REM, 3 * C - 1, 0, 0), (P.DIV0, 2 * C, 0, 0), (P.NOT_FIRST, 1, 0, 0), (P.ZERO, 1, 0, 0), (P.ZERO, 1, 0, 0)]
+    return [P.Instr(form, [(3 * t + (0 if rep else j)) % n_mem for j in range(n)], bits) for t, (form, n, bits, rep) in enumerate(rows)]
 
 
 def run_primary(cfg, tr, vt):

@@ -9,13 +9,19 @@ following the reference:
                                    co-jolt/src/jolt/vm/instruction_lookups/worker.rs:375-720 (LowToHigh binding, `degree`
                                    evaluations at 0, 2, .., degree per round; the coordinator inserts claim - e(0))
   prove_primary_sumcheck_rep3      co-jolt/src/jolt/vm/instruction_lookups/coordinator.rs:97-150
-  combine_lookups_rep3_batched     the three collation FORMS a sha2-style trace needs:
-      CONCAT   (AND / OR / XOR / ADD-like)   co-jolt/src/jolt/instruction/and.rs:89-101 ->
+  combine_lookups_rep3_batched     the collation FORMS of all 27 RV32I instructions (jolt/vm/rv32i_vm.rs:41-70):
+      CONCAT   (ADD SUB AND OR XOR SLL MUL MULU MULHU ADVICE MOVE; bits = 0: SRA / SRL sums; repeated memory: MOVSIGN)
+                                             co-jolt/src/jolt/instruction/and.rs:89-101 ->
                                              concatenate_lookups_rep3_batched, co-jolt/src/utils/instruction_utils.rs:26-47
-      PRODUCT  (BEQ-like)                    co-jolt/src/jolt/instruction/beq.rs:106-130 -> rep3::arithmetic::product_many,
+      PRODUCT / NOT_PRODUCT (BEQ / BNE)      beq.rs:106-130, bne.rs:108-140 -> rep3::arithmetic::product_many,
                                              mpc-core/src/protocols/rep3/arithmetic.rs:86-102
-      LTU      (SLTU-like)                   co-jolt/src/jolt/instruction/sltu.rs:139-170 (mul_vec chain over the EQ
-                                             subtable evaluations, reshare_additive_many of the sum)
+      LTU / NOT_LTU (SLTU / BGEU)            sltu.rs:139-170 (mul_vec chain over the EQ subtable evaluations,
+                                             reshare_additive_many of the sum), bgeu.rs:113-132
+      SLT / NOT_SLT (SLT / BGE)              slt.rs:184-302, bge.rs:121-140
+      LTE, UNSIGNED_REM, DIV0, NOT_FIRST, ZERO   virtual_assert_lte.rs:144-209, virtual_assert_valid_unsigned_remainder.rs:154-249,
+                                             virtual_assert_valid_div0.rs (plain formula :36-42), virtual_assert_halfword_alignment.rs:111-125,
+                                             virtual_pow2.rs:70-78
+      SIGNED_REM                             virtual_assert_valid_signed_remainder.rs:40-67 (its Rep3 body is todo!() upstream)
   utils/future.rs:48-69 (fufill_batched) is what batches the multiplications of one level into one mul_vec.
 
 Three parties run in lock-step; `mul` = local product (+ a zero-sharing mask, zero here: masks cancel in every sum the
@@ -26,22 +32,46 @@ import pyref as O
 
 R = O.R
 
-CONCAT, PRODUCT, LTU = 0, 1, 2
+CONCAT, PRODUCT, LTU, NOT_PRODUCT, NOT_LTU, SLT, NOT_SLT, LTE, NOT_FIRST, DIV0, UNSIGNED_REM, SIGNED_REM, ZERO = range(13)
 
 
 class Instr:
-    """form: CONCAT (mems = C memories, `bits` = operand bits per chunk), PRODUCT (mems = the factors),
-    LTU (mems = C LTU memories followed by C - 1 EQ memories)"""
+    """form + the instruction's memories in the order the form lists them (include/cozk.h COZK_G_*):
+    CONCAT (mems = the chunks, `bits` = operand bits per chunk; bits = 0: plain sum), PRODUCT / NOT_PRODUCT (the factors),
+    LTU / NOT_LTU (C LTU then C - 1 EQ), SLT / NOT_SLT (left_msb, right_msb, C - 1 LTU, C - 2 EQ, lt_abs, eq_abs),
+    LTE (C LTU, C EQ), NOT_FIRST (1 - the first memory), DIV0 (C left_is_zero, C div_by_zero),
+    UNSIGNED_REM (C LTU, C - 1 EQ, C right_is_zero), SIGNED_REM (left_msb, right_msb, C - 1 EQ, C - 1 LTU, eq_abs, lt_abs,
+    C left_is_zero, C right_is_zero), ZERO"""
 
     def __init__(self, form, mems, bits=0):
         self.form, self.mems, self.bits = form, list(mems), bits
 
+    def chunks(self):
+        n, f = len(self.mems), self.form
+        if f in (LTU, NOT_LTU):
+            return (n + 1) // 2
+        if f in (SLT, NOT_SLT):
+            return (n - 1) // 2
+        if f in (LTE, DIV0):
+            return n // 2
+        if f == UNSIGNED_REM:
+            return (n + 1) // 3
+        if f == SIGNED_REM:
+            return (n - 2) // 4
+        return n
+
     def g_degree(self):
-        if self.form == CONCAT:
+        """degree of g in the E's.  The reference's g_poly_degree agrees except for SLT / BGE, where slt.rs:61-63 says
+        C + 1 for a polynomial of degree C + 2 (EQ(x_s, y_s) has degree 2, the LTU sum degree C); harmless in the RV32I set,
+        whose maximum, C + 2, comes from the signed remainder (virtual_assert_valid_signed_remainder.rs:69-71)."""
+        f, C = self.form, self.chunks()
+        if f in (CONCAT, NOT_FIRST, ZERO):
             return 1
-        if self.form == PRODUCT:
+        if f in (PRODUCT, NOT_PRODUCT):
             return len(self.mems)
-        return (len(self.mems) + 1) // 2  # LTU: C
+        if f in (LTU, NOT_LTU, LTE, DIV0, UNSIGNED_REM):
+            return C
+        return C + 2  # SLT, NOT_SLT, SIGNED_REM
 
 
 def sumcheck_degree(instrs):
@@ -66,12 +96,57 @@ def _reshare_additive_many(adds):
     return [[(adds[p][j], adds[(p + 2) % 3][j]) for j in range(len(adds[p]))] for p in range(3)]
 
 
+def _product_many(cols):
+    """rep3::arithmetic::product_many (mpc-core rep3/arithmetic.rs:86-102): fold of mul_vec; cols[t][p][j]"""
+    acc = [list(c) for c in cols[0]]
+    for t in range(1, len(cols)):
+        acc = _mul_vec(acc, cols[t])
+    return acc
+
+
+def _add_public(x, c, p, np_):
+    """rep3::arithmetic::add_public: party 0 adds to a, party 1 to b; the plain prover to its value"""
+    if np_ == 1:
+        return (x + c) % R
+    return ((x[0] + c) % R, x[1]) if p == 0 else ((x[0], (x[1] + c) % R) if p == 1 else x)
+
+
+def _neg(x):
+    return O.sh_sub(O.sh_zero(x), x)
+
+
+def _one_minus(col, p, np_):
+    """sub_public_by_shared(1, x, id)"""
+    return [_add_public(_neg(x), 1, p, np_) for x in col]
+
+
+def _ltu_sum_additive(ltu, eq_first, eq_rest, np_):
+    """the loop shared by sltu.rs:152-169, virtual_assert_lte.rs:163-190, slt.rs:215-249: sums = into_additive(ltu_0),
+    eq_prods = eq_first; for every further ltu_i: sums += ltu_i * eq_prods (local), then eq_prods = mul_vec(eq_prods, next eq)
+    while one is left.  Returns (additive sums per party, eq_prods as shares per party)."""
+    sums = [[O.sh_into_additive(x) for x in ltu[0][p]] for p in range(np_)]
+    eq_prods = [list(eq_first[p]) for p in range(np_)]
+    rest = list(eq_rest)
+    for i in range(1, len(ltu)):
+        for p in range(np_):
+            sums[p] = [(s + O.sh_local_mul(l, e)) % R for s, l, e in zip(sums[p], ltu[i][p], eq_prods[p])]
+        if rest:
+            eq_prods = _mul_vec(eq_prods, rest.pop(0))
+    return sums, eq_prods
+
+
 def combine_lookups_batched(instr, vals):
     """combine_lookups_rep3_batched: vals[p][m][j] = party p's evaluation of the instruction's m-th memory for item j
     -> per party a list of Rep3 shares (plain: values) of g over the items"""
     np_ = len(vals)
     n = len(vals[0][0])
-    if instr.form == CONCAT:  # instruction_utils.rs:26-47
+    f = instr.form
+    col = lambda m: [vals[p][m] for p in range(np_)]  # memory m as [party][item]
+    if f == ZERO:  # virtual_pow2.rs:70-78
+        return [[O.sh_zero(vals[p][0][0])] * n for p in range(np_)]
+    if f == NOT_FIRST:  # virtual_assert_halfword_alignment.rs:111-125
+        return [_one_minus(vals[p][0], p, np_) for p in range(np_)]
+    if f == CONCAT:  # instruction_utils.rs:26-47
         C = len(instr.mems)
         shift = 1 << instr.bits
         out = []
@@ -83,42 +158,136 @@ def combine_lookups_batched(instr, vals):
                 weight = weight * shift % R
             out.append(sums)
         return out
-    if instr.form == PRODUCT:  # product_many: fold of mul_vec
-        acc = [list(vals[p][0]) for p in range(np_)]
-        for m in range(1, len(instr.mems)):
-            acc = _mul_vec(acc, [vals[p][m] for p in range(np_)])
-        return acc
-    # LTU (sltu.rs:139-170)
-    C = (len(instr.mems) + 1) // 2
-    ltu = [[vals[p][i] for i in range(C)] for p in range(np_)]
-    eq = [[vals[p][C + i] for i in range(C - 1)] for p in range(np_)]
-    sums = [[O.sh_into_additive(x) for x in ltu[p][0]] for p in range(np_)]
-    eq_prods = [list(eq[p][0]) for p in range(np_)]
-    for i in range(1, C - 1):
+    if f in (PRODUCT, NOT_PRODUCT):  # beq.rs:106-130, bne.rs:108-140
+        acc = _product_many([col(m) for m in range(len(instr.mems))])
+        return acc if f == PRODUCT else [_one_minus(acc[p], p, np_) for p in range(np_)]
+    C = instr.chunks()
+    if f in (LTU, NOT_LTU):  # sltu.rs:139-170, bgeu.rs:113-132
+        ltu = [col(i) for i in range(C)]
+        eq = [col(C + i) for i in range(C - 1)]
+        if C == 1:
+            return ltu[0] if f == LTU else [_one_minus(ltu[0][p], p, np_) for p in range(np_)]
+        sums, _ = _ltu_sum_additive(ltu, eq[0], eq[1:], np_)
+        res = _reshare_additive_many(sums)
+        return res if f == LTU else [_one_minus(res[p], p, np_) for p in range(np_)]
+    if f == LTE:  # virtual_assert_lte.rs:144-209: the loop runs over all C chunks, then + into_additive(eq_prods)
+        ltu = [col(i) for i in range(C)]
+        eq = [col(C + i) for i in range(C)]
+        sums, eq_prods = _ltu_sum_additive(ltu, eq[0], eq[1:], np_)
+        return _reshare_additive_many([[(s + O.sh_into_additive(e)) % R for s, e in zip(sums[p], eq_prods[p])] for p in range(np_)])
+    if f == UNSIGNED_REM:  # virtual_assert_valid_unsigned_remainder.rs:154-249
+        ltu = [col(i) for i in range(C)]
+        eq = [col(C + i) for i in range(C - 1)]
+        div_zero = _product_many([col(2 * C - 1 + i) for i in range(C)])
+        if C == 1:
+            return [[O.sh_add(a, b) for a, b in zip(ltu[0][p], div_zero[p])] for p in range(np_)]
+        sums, _ = _ltu_sum_additive(ltu, eq[0], eq[1:], np_)
+        res = _reshare_additive_many(sums)
+        return [[O.sh_add(a, b) for a, b in zip(res[p], div_zero[p])] for p in range(np_)]
+    if f == DIV0:
+        # virtual_assert_valid_div0.rs: the PLAIN formula (:36-42) 1 - divisor_is_zero + is_valid_div_by_zero.  The Rep3 body
+        # (:159-225) subtracts the SUM of the two products from 1 -- a sign slip its own plain verifier rejects; not reproduced.
+        a = _product_many([col(i) for i in range(C)])
+        b = _product_many([col(C + i) for i in range(C)])
+        return [[_add_public(O.sh_sub(y, x), 1, p, np_) for x, y in zip(a[p], b[p])] for p in range(np_)]
+    if f in (SLT, NOT_SLT):  # slt.rs:184-302
+        l, r = col(0), col(1)
+        ltu = [col(2 + i) for i in range(C - 1)]
+        eq = [col(C + 1 + i) for i in range(C - 2)]
+        lt_abs, eq_abs = col(2 * C - 1), col(2 * C)
+        ltu_sums = [[O.sh_into_additive(x) for x in lt_abs[p]] for p in range(np_)]
+        eq_prods = [list(eq_abs[p]) for p in range(np_)]
+        for i in range(C - 2):
+            for p in range(np_):
+                ltu_sums[p] = [(s + O.sh_local_mul(x, e)) % R for s, x, e in zip(ltu_sums[p], ltu[i][p], eq_prods[p])]
+            eq_prods = _mul_vec(eq_prods, eq[i])
+        ltu_sum_eq_prod = [[(s + O.sh_local_mul(x, e)) % R for s, x, e in zip(ltu_sums[p], ltu[C - 2][p], eq_prods[p])] for p in range(np_)]
+        nl = [_one_minus(l[p], p, np_) for p in range(np_)]
+        nr = [_one_minus(r[p], p, np_) for p in range(np_)]
+        lm = lambda xs, ys: [[O.sh_local_mul(x, y) for x, y in zip(xs[p], ys[p])] for p in range(np_)]
+        l_nr, l_r, nl_nr, S = (_reshare_additive_many(v) for v in (lm(l, nr), lm(l, r), lm(nl, nr), ltu_sum_eq_prod))
+        eq_s = [[O.sh_add(x, y) for x, y in zip(l_r[p], nl_nr[p])] for p in range(np_)]
+        prod = _mul_vec(eq_s, S)
+        res = [[O.sh_add(x, y) for x, y in zip(l_nr[p], prod[p])] for p in range(np_)]
+        return res if f == SLT else [_one_minus(res[p], p, np_) for p in range(np_)]
+    # SIGNED_REM: virtual_assert_valid_signed_remainder.rs:40-67 (plain); the Rep3 body (:265-273) is todo!() in the
+    # reference -- the schedule below is the straightforward one (product_many / mul_vec of every product)
+    l, r = col(0), col(1)
+    eq = [col(2 + i) for i in range(C - 1)]
+    ltu = [col(C + 1 + i) for i in range(C - 1)]
+    eq_abs, lt_abs = col(2 * C), col(2 * C + 1)
+    ltu_sums = [[O.sh_into_additive(x) for x in lt_abs[p]] for p in range(np_)]
+    eq_prods = [list(eq_abs[p]) for p in range(np_)]
+    for i in range(C - 1):
         for p in range(np_):
-            sums[p] = [(s + O.sh_local_mul(l, e)) % R for s, l, e in zip(sums[p], ltu[p][i], eq_prods[p])]
-        eq_prods = _mul_vec(eq_prods, [eq[p][i] for p in range(np_)])
-    fin = [[(s + O.sh_local_mul(l, e)) % R for s, l, e in zip(sums[p], ltu[p][C - 1], eq_prods[p])] for p in range(np_)]
-    return _reshare_additive_many(fin)
+            ltu_sums[p] = [(s + O.sh_local_mul(x, e)) % R for s, x, e in zip(ltu_sums[p], ltu[i][p], eq_prods[p])]
+        eq_prods = _mul_vec(eq_prods, eq[i])
+    S = _reshare_additive_many(ltu_sums)
+    rem_zero = _product_many([col(2 * C + 2 + i) for i in range(C)])
+    div_zero = _product_many([col(3 * C + 2 + i) for i in range(C)])
+    nl = [_one_minus(l[p], p, np_) for p in range(np_)]
+    lr = _mul_vec(l, r)
+    nlr = _mul_vec(nl, r)
+    one_l_r = [[O.sh_sub(x, y) for x, y in zip(nl[p], r[p])] for p in range(np_)]
+    t1 = _mul_vec(one_l_r, S)
+    t2 = _mul_vec(lr, [_one_minus(eq_prods[p], p, np_) for p in range(np_)])
+    t3 = _mul_vec(nlr, rem_zero)
+    return [[O.sh_add(O.sh_add(a, b), O.sh_add(c, d)) for a, b, c, d in zip(t1[p], t2[p], t3[p], div_zero[p])] for p in range(np_)]
 
 
 def g_plain(instr, e):
-    """g_i on plain values e[m] of its memories"""
-    if instr.form == CONCAT:
-        C = len(instr.mems)
-        return sum(e[m] << (instr.bits * (C - 1 - m)) for m in range(C)) % R
-    if instr.form == PRODUCT:
-        v = 1
-        for x in e:
-            v = v * x % R
-        return v
-    C = (len(instr.mems) + 1) // 2
-    s, prod = 0, 1
-    for i in range(C):
-        s = (s + e[i] * prod) % R
-        if i < C - 1:
-            prod = prod * e[C + i] % R
-    return s
+    """g_i on plain values e[m] of its memories: the plain combine_lookups of co-jolt/src/jolt/instruction/*.rs"""
+    f = instr.form
+    n = len(e)
+    prod = lambda xs: __import__("functools").reduce(lambda a, b: a * b % R, xs, 1)
+
+    def ltu_sum(ltu, eq):
+        s, pr = 0, 1
+        for i, x in enumerate(ltu):
+            s = (s + x * pr) % R
+            if i < len(eq):
+                pr = pr * eq[i] % R
+        return s, pr
+
+    if f == ZERO:
+        return 0
+    if f == NOT_FIRST:
+        return (1 - e[0]) % R
+    if f == CONCAT:
+        return sum(e[m] << (instr.bits * (n - 1 - m)) for m in range(n)) % R
+    if f == PRODUCT:
+        return prod(e)
+    if f == NOT_PRODUCT:
+        return (1 - prod(e)) % R
+    C = instr.chunks()
+    if f in (LTU, NOT_LTU):
+        s, _ = ltu_sum(e[:C], e[C:2 * C - 1])
+        return s if f == LTU else (1 - s) % R
+    if f == LTE:
+        s, pr = ltu_sum(e[:C], e[C:2 * C])
+        return (s + pr) % R
+    if f == UNSIGNED_REM:
+        s, _ = ltu_sum(e[:C], e[C:2 * C - 1])
+        return (s + prod(e[2 * C - 1:3 * C - 1])) % R
+    if f == DIV0:
+        return (1 - prod(e[:C]) + prod(e[C:2 * C])) % R
+    if f in (SLT, NOT_SLT):
+        l, r, ltu, eq, lt_abs, eq_abs = e[0], e[1], e[2:C + 1], e[C + 1:2 * C - 1], e[2 * C - 1], e[2 * C]
+        s, pr = lt_abs, eq_abs
+        for i in range(C - 1):
+            s = (s + ltu[i] * pr) % R
+            if i < C - 2:
+                pr = pr * eq[i] % R
+        g = (l * (1 - r) + (l * r + (1 - l) * (1 - r)) * s) % R
+        return g if f == SLT else (1 - g) % R
+    # SIGNED_REM
+    l, r, eq, ltu, eq_abs, lt_abs = e[0], e[1], e[2:C + 1], e[C + 1:2 * C], e[2 * C], e[2 * C + 1]
+    s, pr = lt_abs, eq_abs
+    for x, q in zip(ltu, eq):
+        s = (s + x * pr) % R
+        pr = pr * q % R
+    rem_zero, div_zero = prod(e[2 * C + 2:3 * C + 2]), prod(e[3 * C + 2:4 * C + 2])
+    return ((1 - l - r) * s + l * r * (1 - pr) + (1 - l) * r * rem_zero + div_zero) % R
 
 
 # ------------------------------------------------------------------------------------------------ one round

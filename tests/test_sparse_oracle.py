@@ -146,6 +146,37 @@ def test_primary_sumcheck_oracle_plain_equals_rep3_and_verifies():
         assert a["proof_bytes"] == b["proof_bytes"]
 
 
+def test_every_rv32i_collation_rep3_schedule_opens_to_the_plain_formula():
+    """all 27 instruction rows of the harness table (13 collation forms): the Rep3 schedule of combine_lookups_rep3_batched,
+    run by three lock-step parties, opens to the plain combine_lookups on the same values -- also for C = 2, 3 shapes"""
+    import pyprimary as P
+    rng = O.SplitMix64(77)
+    table = pylookups.instr_table(64)
+    extra = [P.Instr(P.SLT, range(5)), P.Instr(P.SLT, range(7)), P.Instr(P.NOT_SLT, range(7)), P.Instr(P.SIGNED_REM, range(10)),
+             P.Instr(P.SIGNED_REM, range(14)), P.Instr(P.LTE, range(2)), P.Instr(P.LTE, range(4)), P.Instr(P.DIV0, range(2)),
+             P.Instr(P.UNSIGNED_REM, range(2)), P.Instr(P.UNSIGNED_REM, range(5)), P.Instr(P.LTU, range(1)), P.Instr(P.NOT_LTU, range(3)),
+             P.Instr(P.PRODUCT, range(1)), P.Instr(P.NOT_PRODUCT, range(2))]
+    assert len(table) == 27 and {i.form for i in table} == set(range(13))
+    assert P.sumcheck_degree(table) == 8
+    for instr in table + extra:
+        nm, items = len(instr.mems), 5
+        plain = [[rng.field() for _ in range(items)] for _ in range(nm)]
+        shares = [[O.rep3_share(v, rng) for v in row] for row in plain]
+        vals = [[[shares[m][j][p] for j in range(items)] for m in range(nm)] for p in range(3)]
+        out3 = P.combine_lookups_batched(instr, vals)
+        out1 = P.combine_lookups_batched(instr, [plain])
+        for j in range(items):
+            want = P.g_plain(instr, [plain[m][j] for m in range(nm)])
+            assert sum(O.sh_into_additive(out3[p][j]) for p in range(3)) % R == want, (instr.form, nm)
+            assert out1[0][j] % R == want, (instr.form, nm)
+
+
+def test_primary_sumcheck_oracle_covers_every_instruction_at_2p7():
+    a = pylookups.run(dict(mode="plain", log_n=7, n_pairs=54, density_pct=30, seed=6, primary=1))
+    b = pylookups.run(dict(mode="rep3", log_n=7, n_pairs=54, density_pct=30, seed=6, primary=1))
+    assert a["verified"] and b["verified"] and a["proof_bytes"] == b["proof_bytes"]
+
+
 def test_spartan_outer_oracle_verifies_and_plain_equals_rep3():
     """oracle/pyspartan_outer.py: the sparse SharedOrPublic walk with the Gruen split-eq verifies, its claims
     are the multilinear extensions of the clear Az, Bz, Cz, and the plain and the 3-party run give the same bytes"""
