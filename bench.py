@@ -38,7 +38,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
-# one mixed XYZZ addition in the gather kernel (csrc/fq9.cuh madd9) = 6 products (2 x 81 mads each: limb products +
+# one mixed XYZZ addition in the gather kernel (csrc/fq9.hip.hpp madd9) = 6 products (2 x 81 mads each: limb products +
 # Montgomery reduction) + 2 squarings (45 + 81) + Y3's two products under one reduction (81 + 81 + 81) = 1467 mads
 # = 9.06 stand-alone products of 162 mads, which is what the measured multiplier peak counts
 MADS_PER_MADD = 6 * 162 + 2 * 126 + 243
@@ -55,6 +55,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--leaf-fingerprints", action="store_true",
                     help="compute the grand-product leaves as K11 fingerprints of committed columns (not available with --shard worker)")
+    ap.add_argument("--lookups", action="store_true",
+                    help="add SURVEY 8(f)1 to every step: Lasso's primary sumcheck over the 27 RV32I collations + the toggled / sparse grand "
+                         "product of the instruction lookups (54 memories = 108 circuits, 10 %% flags) on the same 2^log_n-cycle trace (N = 1)")
+    ap.add_argument("--outer", action="store_true",
+                    help="add SURVEY 8(f)2 to every step: the Spartan outer sumcheck over sparse Az / Bz / Cz of the same number of steps (N = 1)")
     ap.add_argument("--host-witness", action="store_true",
                     help="also time the H2D upload of a host-resident witness of the same size (pinned memory) and report the "
                          "PCIe-inclusive step beside `value` (which never includes PCIe)")
@@ -181,7 +186,19 @@ def run_rank(args):
     else:
         h = pkg.Harness(mode="plain", log_n=log_n, seed=dist.shard_seed(2026, rank), devices=(dev, dev, dev), leaf_fingerprints=args.leaf_fingerprints,
                         **workload)
-    t_setup = time.time() - t_setup
+    t_setup_main = time.time() - t_setup
+
+    # optional 8(f) phases of the step (off by default: the headline is quoted on the 8(a) path above)
+    extra = []
+    if (args.lookups or args.outer) and world != 1:
+        raise SystemExit("--lookups / --outer are single-GPU phases (N = 1)")
+    if args.lookups:
+        LK = importlib.import_module("co-zkvms_amd.lookups")
+        extra.append(("lookups", LK.LookupsHarness(mode="plain", log_n=log_n, n_pairs=54, density_pct=10, seed=2026, devices=(dev, dev, dev), primary=True)))
+    if args.outer:
+        OU = importlib.import_module("co-zkvms_amd.outer")
+        extra.append(("outer", OU.OuterHarness(mode="plain", log_steps=log_n, seed=2026, devices=(dev, dev, dev))))
+    t_setup = t_setup_main
 
     # correctness gate (untimed): the assembled proof verifies (GKR, leaf evaluation, reduction sumcheck,
     # PST13 opening with the trapdoor)
@@ -189,8 +206,16 @@ def run_rank(args):
     if res.verified != 1:
         raise SystemExit("proof rejected: " + h.last_error())
     digest0 = bytes(res.proof_digest)
+    extra_digest = {}
+    for name, eh in extra:
+        er = eh.prove(verify=True)
+        if er.verified != 1:
+            raise SystemExit(name + " proof rejected: " + eh.last_error())
+        extra_digest[name] = bytes(er.proof_digest)
     for _ in range(max(0, args.warmup - 1)):
         h.prove(verify=False)
+        for _, eh in extra:
+            eh.prove(verify=False)
 
     hprof.prof_enable(h, 0, True)
     grp.barrier()
@@ -206,6 +231,16 @@ def run_rank(args):
         phases["open"] += r.t_open_ms
         if bytes(r.proof_digest) != digest0:
             raise SystemExit("non-deterministic proof across steps")
+        for name, eh in extra:
+            er = eh.prove(verify=False)
+            if bytes(er.proof_digest) != extra_digest[name]:
+                raise SystemExit("non-deterministic %s proof across steps" % name)
+            if name == "lookups":
+                for k, v in (("lookups_primary_sumcheck", er.t_primary_ms), ("lookups_gp_construct", er.t_construct_ms), ("lookups_gp_prove", er.t_prove_ms)):
+                    phases[k] = phases.get(k, 0.0) + v
+            else:
+                phases["outer_build_AzBzCz"] = phases.get("outer_build_AzBzCz", 0.0) + er.t_build_ms
+                phases["outer_sumcheck"] = phases.get("outer_sumcheck", 0.0) + er.t_prove_ms
     torch.cuda.synchronize(dev)
     grp.barrier()
     dt = time.perf_counter() - t0
@@ -250,7 +285,7 @@ def run_rank(args):
                                          "algorithmic_bytes_per_launch": int(kp["alg_bytes"] / kp["launches"]),
                                          "share_of_step": round(kp["total_ms"] / (dt * 1e3), 4)}
     # the honest ceiling of the dominant kernel is the integer ALU: the measured peak of the multiplier the
-    # gather kernel uses (variant 2 = 9 x 29-bit unsaturated limbs, 162 mads per product; fq9.cuh), best of 7 runs so that
+    # gather kernel uses (variant 2 = 9 x 29-bit unsaturated limbs, 162 mads per product; fq9.hip.hpp), best of 7 runs so that
     # the denominator does not move between runs; variant 1 = the saturated 8 x 32 multiplier, reported beside it
     ctx = pkg.Context(dev)
     lanes = 256 * 256 * 16
@@ -273,7 +308,9 @@ def run_rank(args):
            "dtype": "u32-limb BN254 Fr/Fq (254-bit Montgomery integers)", "data": "synthetic",
            "config": {"workload": "configs[1] restated (SURVEY 8d): 2^%d-cycle trace per GPU, plain prover, 128 polys "
                                   "(64 Fr + 32 u16 + 16 u32 + 16 flags) PST13 batch commit, dense grand product 8 x 2^%d leaves, "
-                                  "batch evaluate + opening reduction + PST13 open" % (log_n, log_n + 1),
+                                  "batch evaluate + opening reduction + PST13 open" % (log_n, log_n + 1)
+                                  + ("; + 8(f)1 Lasso primary sumcheck (27 RV32I collations) and toggled grand product, 54 memories" if args.lookups else "")
+                                  + ("; + 8(f)2 Spartan outer sumcheck over sparse Az/Bz/Cz" if args.outer else ""),
                       "log_n": log_n, "polys": 128, "gp_batch": 8,
                       "parallelism": ("single GPU" if world == 1 else
                                       ("one proof of a 2^%d-cycle trace sharded over %d worker sub-nets (high-variable chunks), star all-gather per round" % (total_log_n, world)
@@ -310,6 +347,8 @@ def run_rank(args):
                                              "2^22_cycles_32_vcpu": {"cycles_per_s": 12200, "prove_s": 345.9, "commit_s": 146.0}}}
     if rank == 0:
         print(json.dumps(out), flush=True)
+    for _, eh in extra:
+        eh.close()
     h.close()
     grp.close()
 

@@ -1,7 +1,7 @@
 // libcozk C ABI: context, device vectors, synthetic data, micro-benchmarks.
 #include "common.hpp"
-#include "fq9.cuh"
-#include "prf.cuh"
+#include "fq9.hip.hpp"
+#include "prf.hip.hpp"
 
 // ------------------------------------------------------------------ synthetic data
 static __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
@@ -12,7 +12,7 @@ static __device__ __forceinline__ uint64_t splitmix_next(uint64_t& s) {
     return z ^ (z >> 31);
 }
 
-// SYNTHETIC DATA ONLY (never secret randomness -- that is prf.cuh): element i draws from its own SplitMix64 stream
+// SYNTHETIC DATA ONLY (never secret randomness -- that is prf.hip.hpp): element i draws from its own SplitMix64 stream
 // seeded with seed + i * 0xD1342543DE82EF95 (oracle/pyref.py `synthetic_fr` restates this).  FR: rejection-sample a canonical value < r
 // (top word masked to 62 bits), optionally masked to max_bits, stored in Montgomery form.
 __global__ void k_fill_random_fr(fe* out, size_t n, uint64_t seed, int max_bits) {
@@ -90,7 +90,7 @@ __global__ void __launch_bounds__(256) k_bench_montmul(fe* x, int iters) {
     if (VARIANT == 0) {
         for (int k = 0; k < iters; k++) a = Fq::mul(a, b);
     } else if (VARIANT == 2) {
-        // the 9 x 29-bit unsaturated multiplier of the MSM gather kernel (fq9.cuh)
+        // the 9 x 29-bit unsaturated multiplier of the MSM gather kernel (fq9.hip.hpp)
         f9 x9 = f9_from_fe(a), y9 = f9_from_fe(b);
         for (int k = 0; k < iters; k++) x9 = f9_mul(x9, y9);
         a = f9_to_fe(x9);
@@ -239,7 +239,7 @@ void* cozk_vec_device_ptr(const cozk_vec* v) { return v ? v->d : nullptr; }
 
 // Rep3 sharing of a secret vector on the device (rep3::share_field_element, mpc-core/src/protocols/rep3/arithmetic.rs:
 // 21-33; the witness scatter of jolt/vm/*/witness.rs generate_poly_shares_rep3): t0 = PRF(key0, .), t1 = PRF(key1, .)
-// (ChaCha12, prf.cuh), t2 = v - t0 - t1; party 0 holds (t0, t2), party 1 (t1, t0), party 2 (t2, t1).  One fused pass.
+// (ChaCha12, prf.hip.hpp), t2 = v - t0 - t1; party 0 holds (t0, t2), party 1 (t1, t0), party 2 (t2, t1).  One fused pass.
 // (The reference's generate_poly_shares_rep3 repeats ONE random element over the whole vector, SURVEY 9: not copied.)
 __global__ void __launch_bounds__(256) k_rep3_share(const fe* __restrict__ v, size_t n, prf_key key0, prf_key key1, uint64_t ctr, int party,
                                                     fe* __restrict__ a, fe* __restrict__ b) {

@@ -12,7 +12,7 @@
 #include <stdexcept>
 
 #include "../../include/cozk.h"
-#include "ec.cuh"
+#include "ec.hip.hpp"
 
 struct CozkError : std::runtime_error {
     int code;

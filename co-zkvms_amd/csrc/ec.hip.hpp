@@ -2,7 +2,7 @@
 //
 // Bucket accumulators use extended-Jacobian "XYZZ" coordinates (x = X/ZZ, y = Y/ZZZ, ZZ^3 = ZZZ^2):
 // mixed addition of an affine SRS point costs 8M + 2S with no inversion, full addition 12M + 2S.
-// XYZZ coordinates live in the lazy range [0, 2p) on the device (ff.cuh l-operations: products skip their
+// XYZZ coordinates live in the lazy range [0, 2p) on the device (ff.hip.hpp l-operations: products skip their
 // final conditional subtraction); affine points are always canonical, and to_affine canonicalises.  The
 // P == Q / P == -Q special cases are detected by a zero test that accepts 0 and p; every formula handles
 // identity, doubling and cancellation, because bucket contents arrive in arbitrary (atomic-scatter) order
@@ -10,7 +10,7 @@
 // Result convention at the C ABI: affine, Montgomery, LE limbs -- what `into_affine()` yields at
 // co-jolt/src/poly/commitment/pst13.rs:294,328.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.hpp"
 
 struct alignas(16) g1_affine {  // 64 B; infinity is encoded as (0, 0), which is not on the curve
     fe x, y;

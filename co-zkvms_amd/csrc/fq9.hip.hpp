@@ -22,7 +22,7 @@
 // formulas of the later fold levels rely on.  Exceptional inputs (P == +-Q, i.e. PP == 0 mod p) are not
 // handled here: the kernel hands the segment to the saturated-limb path.
 #pragma once
-#include "ec.cuh"
+#include "ec.hip.hpp"
 #include "fq9_consts.inc"
 #include "fq9_mac.inc"
 #include "fq9_mul.inc"
@@ -193,7 +193,7 @@ static __device__ __forceinline__ bool madd9(xyzz9& acc, const f9& qx, const f9&
     return true;
 }
 
-// back to an ordinary R-form XYZZ point in the lazy range [0, 2p) of ec.cuh
+// back to an ordinary R-form XYZZ point in the lazy range [0, 2p) of ec.hip.hpp
 static __device__ __forceinline__ g1_xyzz xyzz9_to_xyzz(const xyzz9& a) {
     g1_xyzz r;
     r.x = f9_to_fe(f9_mul(a.x, f9_const(F9_OUT)));

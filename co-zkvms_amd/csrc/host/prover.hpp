@@ -18,7 +18,7 @@
 #include <string.h>
 
 #include "net.hpp"
-#include "../prf.cuh"
+#include "../prf.hip.hpp"
 
 namespace cozk {
 
@@ -99,7 +99,7 @@ struct WorkerEnv {
     int party;  // PartyID 0..2 (0 for the plain prover)
     StarNetWorker* star;
     RingNet* ring;            // null for the plain prover
-    uint8_t key_self[COZK_PRF_KEY_BYTES] = {0};  // 32-byte ChaCha12 PRF key shared with the next party (prf.cuh)
+    uint8_t key_self[COZK_PRF_KEY_BYTES] = {0};  // 32-byte ChaCha12 PRF key shared with the next party (prf.hip.hpp)
     uint8_t key_prev[COZK_PRF_KEY_BYTES] = {0};  // ... with the previous party
     uint64_t mask_ctr = 0;    // zero-sharing counter (advances identically on all parties)
     void set_keys(const uint8_t* self_key, const uint8_t* prev_key) {
@@ -1602,7 +1602,7 @@ static std::vector<fe> rep3_second_sumcheck_worker(WorkerEnv& env, cozk_poly* z,
     return point;
 }
 
-// the tiny per-round masks are made on the host with the same keyed ChaCha12 PRF as the device masks (prf.cuh)
+// the tiny per-round masks are made on the host with the same keyed ChaCha12 PRF as the device masks (prf.hip.hpp)
 static fe spartan_mask_additive(WorkerEnv& env) {
     if (env.mode != COZK_MODE_REP3) return Fr::zero();  // a single party has nothing to hide from itself
     fe m = Fr::sub(prf_fr(prf_key_from_bytes(env.key_self), env.mask_ctr), prf_fr(prf_key_from_bytes(env.key_prev), env.mask_ctr));

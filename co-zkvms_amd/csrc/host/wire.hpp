@@ -14,7 +14,7 @@
 #include <string>
 #include <vector>
 
-#include "../poly.cuh"
+#include "../poly.hip.hpp"
 
 namespace cozk {
 

@@ -20,7 +20,7 @@
 //     latency-bound bucket-reduction tail).
 // Results are returned as affine points, so the output is bit-exact to any correct MSM.
 #include "common.hpp"
-#include "fq9.cuh"
+#include "fq9.hip.hpp"
 
 static constexpr uint32_t NB = 1u << 15;  // buckets per group
 static constexpr int CH = 16;             // buckets per reduction chunk
@@ -507,7 +507,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict_
     segment_range(off_in, off_out, nb, t, begin, end);
     xyzz_store(out + t, gather_segment(table, refs, begin, end));
 }
-// The same gather in 9 x 29-bit unsaturated limbs (fq9.cuh): no carry instructions in the products, no
+// The same gather in 9 x 29-bit unsaturated limbs (fq9.hip.hpp): no carry instructions in the products, no
 // conditional subtractions anywhere.  A segment that meets P == +-Q (repeated SRS points, cancelling digits) is
 // queued in `exc` ([0] = count, [1..] = segment ids) and redone by k_msm_accum0_fix with the saturated formulas.
 template <bool CHECK_INF>

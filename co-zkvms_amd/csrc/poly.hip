@@ -10,8 +10,8 @@
 #include <atomic>
 #include <chrono>
 #include <string.h>
-#include "poly.cuh"
-#include "prf.cuh"
+#include "poly.hip.hpp"
+#include "prf.hip.hpp"
 
 static constexpr int PT = 256;      // threads per block
 static constexpr int MAXBLK = 2048; // grid cap for reducing kernels (>= 8 blocks per CU)
@@ -699,7 +699,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
 
 // out[j] = L[j] x R[j] (+ mask_j): local half of `mul_vec` (layer_output,
 // dense_interleaved_poly.rs:122-141; local product ops.rs:71-78; zero-sharing mask
-// mask_j = PRF(key_self, ctr+j) - PRF(key_prev, ctr+j), the keyed ChaCha12 PRF of prf.cuh)
+// mask_j = PRF(key_self, ctr+j) - PRF(key_prev, ctr+j), the keyed ChaCha12 PRF of prf.hip.hpp)
 template <int NC>
 __global__ void __launch_bounds__(PT) k_layer_output(const fe* __restrict__ a, const fe* __restrict__ b, size_t len,
                                                   fe* __restrict__ out, size_t n_out, int masked, prf_key key_self,

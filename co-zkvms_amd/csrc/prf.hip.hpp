@@ -15,7 +15,7 @@
 // form.  Host and device run the same code (the per-round masks of the co-spartan sumchecks are made on the host).
 // oracle/pyref.py `prf_fr` and oracle/c restate it; the masks cancel in every sum, so proofs do not depend on it.
 #pragma once
-#include "ff.cuh"
+#include "ff.hip.hpp"
 
 struct prf_key {
     uint32_t k[8];

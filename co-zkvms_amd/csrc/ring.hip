@@ -18,8 +18,8 @@
 #include <rccl/rccl.h>
 
 #include "common.hpp"
-#include "poly.cuh"
-#include "prf.cuh"
+#include "poly.hip.hpp"
+#include "prf.hip.hpp"
 
 namespace {
 

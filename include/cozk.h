@@ -92,7 +92,7 @@ void* cozk_vec_device_ptr(const cozk_vec* v);
 int cozk_vec_fill_random(cozk_ctx* ctx, cozk_vec* v, uint64_t seed, int max_bits);
 
 /* Keyed PRF of the engine: PRF(key, j) = element j of the ChaCha12 stream keyed with the 32-byte `key` (one block per
- * element: counter = j, rejection-sampled below r; csrc/prf.cuh).  Keys are what the reference's parties exchange as
+ * element: counter = j, rejection-sampled below r; csrc/prf.hip.hpp).  Keys are what the reference's parties exchange as
  * 32-byte ChaCha seeds (mpc-types/src/protocols/rep3.rs:29,177; mpc-core/src/protocols/rep3/network.rs:190-211) and
  * come from the host's CryptoRng; (key, counter range) pairs must never be reused for different data. */
 #define COZK_PRF_KEY_BYTES 32

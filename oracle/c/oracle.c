@@ -163,7 +163,7 @@ static uint64_t stream_small(uint64_t seed, uint64_t i, int bits) {
     return bits < 64 ? v & (((uint64_t)1 << bits) - 1) : v;
 }
 
-/* ------------------------------------------------------------------ keyed PRF (restates co-zkvms_amd/csrc/prf.cuh and
+/* ------------------------------------------------------------------ keyed PRF (restates co-zkvms_amd/csrc/prf.hip.hpp and
  * oracle/pyref.py prf_fr): element j of a stream = one ChaCha12 block, rejection-sampled below r */
 static uint32_t prf_rotl(uint32_t v, int n) { return (v << n) | (v >> (32 - n)); }
 #define ORC_QR(a, b, c, d) a += b; d ^= a; d = prf_rotl(d, 16); c += d; b ^= c; b = prf_rotl(b, 12); a += b; d ^= a; d = prf_rotl(d, 8); c += d; b ^= c; b = prf_rotl(b, 7);

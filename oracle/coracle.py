@@ -81,7 +81,7 @@ def msm(xy, inf, scalars_mont):
 
 
 def prf_fr(key, counter, n):
-    """PRF(key, counter + i) for i < n as Montgomery limbs (n, 4) -- the C restatement of csrc/prf.cuh"""
+    """PRF(key, counter + i) for i < n as Montgomery limbs (n, 4) -- the C restatement of csrc/prf.hip.hpp"""
     import numpy as np
     out = np.zeros((n, 4), dtype=np.uint64)
     lib().orc_prf_fr(ctypes.c_char_p(bytes(key)), ctypes.c_uint64(counter), ctypes.c_size_t(n), out.ctypes.data_as(ctypes.c_void_p))

@@ -981,7 +981,7 @@ def deser_g1(b):
 
 
 # --------------------------------------------------------------------------------------------
-# keyed PRF of the engine (co-zkvms_amd/csrc/prf.cuh): element j of a stream is one ChaCha12 block.
+# keyed PRF of the engine (co-zkvms_amd/csrc/prf.hip.hpp): element j of a stream is one ChaCha12 block.
 # The reference draws shares and masks from ChaCha12 streams keyed with 32-byte seeds the parties exchange
 # (mpc-types/src/protocols/rep3.rs:29,177; mpc-core/src/protocols/rep3/network.rs:190-211); random access
 # per element replaces the sequential stream.  ChaCha itself is pinned by the RFC 8439 2.3.2 block vector
@@ -1015,7 +1015,7 @@ _PRF_DOMAIN = 0x4B5A4F43  # "COZK"
 
 
 def prf_block(key, counter, attempt):
-    """prf.cuh chacha12_block: state = constants | key | counter (64 bit) | domain | attempt"""
+    """prf.hip.hpp chacha12_block: state = constants | key | counter (64 bit) | domain | attempt"""
     assert len(key) == 32
     k = [int.from_bytes(key[4 * i:4 * i + 4], "little") for i in range(8)]
     st = _CHACHA_CONST + k + [counter & _M32, (counter >> 32) & _M32, _PRF_DOMAIN, attempt]

@@ -1,4 +1,4 @@
-"""CPU model of the 9 x 29-bit unsaturated Fq arithmetic of the MSM gather kernel (co-zkvms_amd/csrc/fq9.cuh):
+"""CPU model of the 9 x 29-bit unsaturated Fq arithmetic of the MSM gather kernel (co-zkvms_amd/csrc/fq9.hip.hpp):
 the same column schedule, constants parsed from the generated fq9_consts.inc, with an assertion on every 64-bit
 accumulator and every 32-bit limb.  Checks (no GPU): (i) the generated constants are what the header says they are;
 (ii) long random chains of mixed additions -- including negated points and worst-case limb patterns -- never

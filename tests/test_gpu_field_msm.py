@@ -153,7 +153,7 @@ def test_msm_repeated_bases_take_the_exception_path(cozk, ctx):
 
 
 def test_prf_stream_matches_oracle(cozk, ctx):
-    """cozk_vec_fill_prf: element j = one ChaCha12 block keyed with the 32-byte key (csrc/prf.cuh) == pyref.prf_fr;
+    """cozk_vec_fill_prf: element j = one ChaCha12 block keyed with the 32-byte key (csrc/prf.hip.hpp) == pyref.prf_fr;
     257 elements cover both halves of a block and the second-attempt path (6 % of the draws)"""
     key = O.harness_prf_key(11, 3)
     for ctr in (0, 12345, (1 << 33) + 7):

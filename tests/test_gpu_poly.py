@@ -316,7 +316,7 @@ def test_layer_output_local_masks_and_claimed_outputs(cozk, ctx, mode):
     plain = layer.layer_output_local().to_ints()
     assert plain == O.interleaved_layer_output_local(coeffs)
     assert layer.claimed_outputs() == O.interleaved_layer_output_local(coeffs)
-    # masked: mask_j = PRF(key_self, ctr + j) - PRF(key_prev, ctr + j)  (keyed ChaCha12, csrc/prf.cuh)
+    # masked: mask_j = PRF(key_self, ctr + j) - PRF(key_prev, ctr + j)  (keyed ChaCha12, csrc/prf.hip.hpp)
     ks, kp = O.harness_prf_key(11, 0), O.harness_prf_key(22, 0)
     got = layer.layer_output_local(masked=True, key_self=ks, key_prev=kp, counter=5).to_ints()
     ms, mp = O.prf_fr_vec(ks, 5, 32), O.prf_fr_vec(kp, 5, 32)

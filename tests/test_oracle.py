@@ -44,7 +44,7 @@ def test_reference_constants():
 
 
 def test_chacha_block_rfc8439_vector_and_prf():
-    """the keyed PRF behind every share / mask (csrc/prf.cuh) is the ChaCha block function; pin the restatement
+    """the keyed PRF behind every share / mask (csrc/prf.hip.hpp) is the ChaCha block function; pin the restatement
     with the RFC 8439 section 2.3.2 block test vector (20 rounds: key 00..1f, counter 1, nonce 00:00:00:09:00:00:00:4a:
     00:00:00:00), then check the 12-round PRF: C restatement == Python restatement, range, determinism, zero-sum masks"""
     key = bytes(range(32))
