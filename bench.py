@@ -301,6 +301,17 @@ def run_rank(args):
                            "note": "mixed XYZZ addition = 6 products + 2 squarings + one fused two-product reduction = 1467 v_mad_u64_u32 "
                                    "= 9.06 products of the 9x29-bit multiplier (162 mads); peak = that multiplier's dependent-product "
                                    "micro-benchmark, best of 7 in this run"}
+    # how full the vector-issue slots of the gather kernel are: SQ counters of a separate rocprofv3 --pmc pass (committed, tagged)
+    try:
+        sq = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_sq.json")))
+        ks = next(v for k, v in sq["kernels"].items() if "k_msm_accum0_f9" in k)
+        if log_n == 20 and world == 1:
+            roofline["int_alu"]["valu_issue_utilisation"] = ks["derived"]["valu_issue_utilisation_same_pass"]
+            roofline["int_alu"]["lane_utilisation"] = ks["derived"]["lane_utilisation"]
+            roofline["int_alu"]["valu_instructions_per_point_add"] = round(ks["SQ_INSTS_VALU"] * 64.0 / (prof["point_adds"] / launches), 1)
+            roofline["int_alu"]["counters_source"] = "profiles/r2_pmc_sq.json (%s); NOT measured in this run" % sq.get("measured_at", "")
+    except Exception:
+        pass
 
     out = {"metric": "RISC-V cycles proved/sec (co-Jolt hot path: PST13 commit + dense GKR grand product + openings)",
            "value": round(value, 1), "unit": "cycles/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
