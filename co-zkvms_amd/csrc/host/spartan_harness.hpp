@@ -3,8 +3,10 @@
 // path -- zero_round (sparse Az, Bz, Cz on shares, :153-182), first_round (PST commit of share_0,
 // :185-193,577-590), second_round (rep3_first_sumcheck_worker, :195-233,593-639), third_round (A(rx,.)
 // build :235-249, rep3_second_sumcheck_worker :641-688, rep3_eval_poly_worker, distributed_open :774-809) --
-// with the calling thread as coordinator + verifier.  fourth_round (public logup over pub_ipk) is SURVEY
-// 8(f) scope and is not part of this harness.  Included by harness.hip (same translation unit).
+// with the calling thread as coordinator + verifier.  cfg.lookup_round adds the PUBLIC part with one public
+// worker on party 0's GPU: third_round's tail (:296-343) and fourth_round (:398-575) -- two logup lookups, the distributed
+// sumcheck over the 13 products, the batch opening of 15 polynomials under ck_index -- verified as spartan/src/logup.rs:117-190
+// does.  Included by harness.hip (same translation unit).
 //
 // Synthetic instance (no Noir front-end on the box), everything derived from `seed`, n = 2^nv rows/columns:
 //   z[i]      = stream(seed + 1000)[i], z[0] = 1 (the constant column of R1CS)
@@ -31,6 +33,13 @@ struct SpartanParty {
     VecH row_ptr, col, va, vb, vc;         // CSR by row (zero_round)
     VecH t_ptr, t_row, t_va, t_vb, t_vc;   // CSR of the transpose: per column, the rows it touches (third_round)
     std::unique_ptr<PST13Setup> setup;
+    // public lookup round (party 0, cfg.lookup_round): the index under ck_index (spartan/src/indexer.rs:176-231)
+    std::unique_ptr<PST13Setup> setup_idx;
+    VecH rows_u32, cols_u32, domain_u32;  // entry -> row / column (the real entries); the domain 0 .. 2^qv - 1
+    VecH val_pad[3];                      // val_a, val_b, val_c padded to 2^qv entries
+    PolyH val_poly[3];
+    VecH freq_r, freq_c;                  // normalized_multiplicities of the padded rows / cols against the domain
+    double t_lookup = 0;
     double t_zero = 0, t_commit = 0, t_sc1 = 0, t_build = 0, t_sc2 = 0, t_open = 0, t_total = 0;
     uint64_t star_up = 0, star_down = 0, star_msgs = 0;
     std::string error;
@@ -44,6 +53,14 @@ struct SpartanProof {
     std::vector<fe> sc2_finals;        // z(ry), A(rx, ry), B(rx, ry), C(rx, ry)
     fe z_eval;                         // rep3_eval_poly_worker's z(ry)
     std::vector<g1_affine> opening;    // nv quotient commitments
+    // cfg.lookup_round (LogLookupProof + the third round's public claims; coordinator.rs:475-591)
+    bool has_lookup = false;
+    std::vector<fe> val_abc;               // val_a, val_b, val_c = sum val * eq_rx[row] * eq_ry[col]
+    g1_affine c_rx, c_ry;                  // commitments of eq_tilde_rx_chunk, eq_tilde_ry_chunk
+    std::vector<g1_affine> h_comms;        // h_0, h_1 of the row lookup, h_0, h_1 of the column lookup
+    std::vector<std::vector<fe>> lk_msgs;  // qv x 4 evaluations at t = 0..3
+    std::vector<fe> lk_evals;              // the 9 committed + 6 public polynomials at the sumcheck's point
+    std::vector<g1_affine> lk_opening;     // qv quotient commitments of the eta-batched opening
     Bytes serialize() const {
         Writer w;
         w.u64(cz.nv);
@@ -56,6 +73,16 @@ struct SpartanProof {
         w.vec_fr(sc2_finals);
         w.fr(z_eval);
         w.vec_g1(opening);
+        if (has_lookup) {
+            w.vec_fr(val_abc);
+            w.g1(c_rx);
+            w.g1(c_ry);
+            for (const auto& c : h_comms) w.g1(c);
+            w.u64(lk_msgs.size());
+            for (auto& r : lk_msgs) w.vec_fr(r);
+            w.vec_fr(lk_evals);
+            w.vec_g1(lk_opening);
+        }
         return w.b;
     }
 };
@@ -70,6 +97,8 @@ struct cozk_spartan {
     // host copy of the instance for the verifier (entry e = 3 row + k)
     std::vector<uint32_t> h_col;
     std::vector<fe> h_va, h_vb, h_vc;
+    int qv = 0;                          // num_variables_val: entries padded to 2^qv (lookup round)
+    std::vector<g1_affine> val_oracles;  // IndexVerifierKey::val_{a,b,c}_oracle (indexer.rs:205-207)
     std::string error;
     Bytes last_proof;
 };
@@ -200,6 +229,254 @@ static void spartan_setup_party(cozk_spartan* h, SpartanParty& ps, const std::ve
     ps.t_vb = upload_fe(ctx, tb);
     ps.t_vc = upload_fe(ctx, tc);
     HIP_TRY(hipStreamSynchronize(ctx->stream));
+    if (c.lookup_round && ps.party == 0) {
+        // the index (spartan/src/indexer.rs:176-231): entries padded to 2^qv, ck_index with qv variables, the val oracles,
+        // multiplicities of the rows / cols padded with their first term against the domain 0 .. 2^qv - 1
+        const int qv = h->qv;
+        const size_t NZ = (size_t)1 << qv;
+        std::vector<fe> ti((size_t)qv);
+        for (int i = 0; i < qv; i++) ti[(size_t)i] = synthetic_fr_host(c.seed ^ 0x1D1D1D1Dull, (uint64_t)i);
+        ps.setup_idx = PST13::setup(ctx, ti, c.precompute);
+        std::vector<uint32_t> rows(nnz), dom(NZ), fr_(NZ, 0), fc_(NZ, 0);
+        for (size_t e = 0; e < nnz; e++) rows[e] = (uint32_t)(e / 3);
+        for (size_t i = 0; i < NZ; i++) dom[i] = (uint32_t)i;
+        for (size_t e = 0; e < NZ; e++) {
+            fr_[e < nnz ? rows[e] : rows[0]]++;
+            fc_[e < nnz ? h->h_col[e] : h->h_col[0]]++;
+        }
+        ps.rows_u32 = upload_u32(ctx, rows);
+        ps.cols_u32 = upload_u32(ctx, h->h_col);
+        ps.domain_u32 = upload_u32(ctx, dom);
+        std::vector<fe> f1(NZ), f2(NZ);
+        for (size_t i = 0; i < NZ; i++) {
+            f1[i] = Fr::from_u64(fr_[i]);
+            f2[i] = Fr::from_u64(fc_[i]);
+        }
+        ps.freq_r = upload_fe(ctx, f1);
+        ps.freq_c = upload_fe(ctx, f2);
+        const std::vector<fe>* vals[3] = {&h->h_va, &h->h_vb, &h->h_vc};
+        std::vector<cozk_vec*> vv;
+        for (int k = 0; k < 3; k++) {
+            std::vector<fe> pad(*vals[k]);
+            pad.resize(NZ, Fr::zero());
+            ps.val_pad[k] = upload_fe(ctx, pad);
+            ps.val_poly[k] = plain_poly_from(ctx, ps.val_pad[k]);
+            vv.push_back(ps.val_pad[k].h);
+        }
+        h->val_oracles.clear();
+        for (const PST13Commitment& cm : PST13::batch_commit(ctx, *ps.setup_idx, vv)) h->val_oracles.push_back(cm.g_product);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    }
+}
+
+// --------------------------------------------------------------------------- public lookup round (cfg.lookup_round)
+// The schedule every participant follows (only party 0 computes; the others answer with empty messages, as the reference's
+// inactive workers answer with defaults, worker.rs:344-361):
+//   resp  val_a, val_b, val_c, C(eq_tilde_rx), C(eq_tilde_ry)          third_round's public tail (worker.rs:296-343)
+//   req   v, x_r, x_c                                                   fourth_round (worker.rs:415, 478-480)
+//   resp  C(h_0), C(h_1) of the row lookup, of the column lookup        (:482-505)
+//   req   z_r, lambda_r, z_c, lambda_c                                  (:507-541)
+//   qv x  resp 4 evaluations / req r                                    distributed_sumcheck_worker (:694-724)
+//   req   eta;  resp the batched opening + the 15 evaluations           distributed_batch_open_poly_worker (:745-772)
+static void spartan_lookup_worker(cozk_spartan* h, SpartanParty& ps, StarNetWorker* star, const std::vector<fe>& rx, const std::vector<fe>& ry,
+                                  const fe coef[3]) {
+    const int qv = h->qv;
+    const size_t NZ = (size_t)1 << qv;
+    cozk_ctx* ctx = ps.ctx;
+    if (ps.party != 0) {
+        star->send_response(Bytes());
+        (void)star->receive_request();
+        star->send_response(Bytes());
+        (void)star->receive_request();
+        for (int j = 0; j < qv; j++) {
+            star->send_response(Bytes());
+            (void)star->receive_request();
+        }
+        (void)star->receive_request();
+        star->send_response(Bytes());
+        return;
+    }
+    auto gather = [&](const VecH& idx, const VecH& src) {
+        cozk_vec* g = nullptr;
+        rc_check(cozk_vec_gather(ctx, idx.h, src.h, NZ, &g), ctx, "vec_gather");
+        return VecH(g);
+    };
+    auto hash = [&](const VecH& idx, const VecH& eq, const fe& v) {
+        uint64_t vv[4];
+        fe_to_u64x4(v, vv);
+        cozk_vec* g = nullptr;
+        rc_check(cozk_hash_tuple(ctx, idx.h, eq.h, vv, NZ, &g), ctx, "hash_tuple");
+        return VecH(g);
+    };
+    // ---- third_round's public tail: eq_tilde_{rx,ry}(_chunk), val_a, val_b, val_c, the two commitments
+    VecH eqrx = eq_le_device(ctx, rx), eqry = eq_le_device(ctx, ry);
+    VecH erx = gather(ps.rows_u32, eqrx), ery = gather(ps.cols_u32, eqry);
+    fe val_abc[3];
+    {
+        cozk_vec* wv = nullptr;
+        rc_check(cozk_vec_alloc(ctx, NZ, COZK_SCALAR_FR, &wv), ctx, "vec_alloc");
+        VecH w(wv);
+        rc_check(cozk_vec_binop(ctx, COZK_OP_MUL, 0, erx.h, ery.h, w.h), ctx, "eq_rx * eq_ry");
+        for (int k = 0; k < 3; k++) {
+            uint64_t a[4], b[4];
+            rc_check(cozk_poly_dot_product_with_public(ctx, ps.val_poly[k].h, w.h, a, b), ctx, "val . eq eq");
+            val_abc[k] = fe_from_u64x4(a);
+        }
+    }
+    {
+        std::vector<PST13Commitment> cm = PST13::batch_commit(ctx, *ps.setup_idx, {erx.h, ery.h});
+        Writer w;
+        w.vec_fr({val_abc[0], val_abc[1], val_abc[2]});
+        w.g1(cm[0].g_product);
+        w.g1(cm[1].g_product);
+        star->send_response(w.b);
+    }
+    // val_m = v_0 val_a + v_1 val_b + v_2 val_c (worker.rs:334-337)
+    PolyH val_m;
+    {
+        const cozk_poly* arr[3] = {ps.val_poly[0].h, ps.val_poly[1].h, ps.val_poly[2].h};
+        uint64_t cf[12];
+        for (int k = 0; k < 3; k++) fe_to_u64x4(coef[k], cf + 4 * k);
+        cozk_poly* vm = nullptr;
+        rc_check(cozk_poly_linear_combination(ctx, arr, cf, 3, COZK_MODE_PLAIN, 0, &vm), ctx, "val_m");
+        val_m = PolyH(vm);
+    }
+    cozk_vec* vmv = nullptr;
+    rc_check(cozk_poly_share_view(ctx, val_m.h, 0, &vmv), ctx, "share_view");
+    VecH val_m_vec(vmv);
+    // ---- fourth_round
+    fe v, x_r, x_c;
+    {
+        Bytes req = star->receive_request();
+        Reader rd(req);
+        v = rd.fr();
+        x_r = rd.fr();
+        x_c = rd.fr();
+    }
+    VecH q_row = hash(ps.rows_u32, erx, v), q_col = hash(ps.cols_u32, ery, v);
+    VecH t_row = hash(ps.domain_u32, erx, v), t_col = hash(ps.domain_u32, ery, v);
+    // LogLookupProof::prove (logup.rs:31-80): phi_0 = x + t, h_0 = m / phi_0, phi_1 = x + q, h_1 = 1 / phi_1 (boost_degree is
+    // the identity here: the table and the query have qv variables each)
+    auto prove = [&](const VecH& query, const VecH& table, const VecH& m, const fe& x, VecH out[4]) {
+        uint64_t xx[4];
+        fe_to_u64x4(x, xx);
+        cozk_vec *phi0 = nullptr, *h0 = nullptr, *phi1 = nullptr, *h1 = nullptr;
+        rc_check(cozk_logup_h(ctx, table.h, m.h, xx, &phi0, &h0), ctx, "logup_h(table)");
+        out[0] = VecH(h0);
+        out[1] = VecH(phi0);
+        rc_check(cozk_logup_h(ctx, query.h, nullptr, xx, &phi1, &h1), ctx, "logup_h(query)");
+        out[2] = VecH(h1);
+        out[3] = VecH(phi1);
+    };
+    VecH lr[4], lc[4];  // h_0, phi_0, h_1, phi_1
+    prove(q_row, t_row, ps.freq_r, x_r, lr);
+    prove(q_col, t_col, ps.freq_c, x_c, lc);
+    {
+        std::vector<PST13Commitment> cm = PST13::batch_commit(ctx, *ps.setup_idx, {lr[0].h, lr[2].h, lc[0].h, lc[2].h});
+        Writer w;
+        for (int i = 0; i < 4; i++) w.g1(cm[i].g_product);
+        star->send_response(w.b);
+    }
+    std::vector<fe> z_r, z_c;
+    fe lam_r, lam_c;
+    {
+        Bytes req = star->receive_request();
+        Reader rd(req);
+        z_r = rd.vec_fr();
+        lam_r = rd.fr();
+        z_c = rd.vec_fr();
+        lam_c = rd.fr();
+        COZK_REQUIRE((int)z_r.size() == qv && (int)z_c.size() == qv, "spartan: lookup z length");
+    }
+    VecH lag_r = eq_le_device(ctx, z_r), lag_c = eq_le_device(ctx, z_c);  // partial_generate_eq over the whole domain
+    // ListOfProductsOfPolynomials (worker.rs:469-541; append_sumcheck_polys, sumcheck.rs:459-500)
+    const cozk_vec* polys[15] = {erx.h,   ery.h,   val_m_vec.h, lag_r.h, lr[0].h, lr[1].h, ps.freq_r.h, lr[2].h,
+                                 lr[3].h, lag_c.h, lc[0].h,     lc[1].h, ps.freq_c.h, lc[2].h, lc[3].h};
+    std::vector<fe> coefs;
+    std::vector<int> counts, factors;
+    auto add_product = [&](const fe& cf, std::initializer_list<int> idx) {
+        coefs.push_back(cf);
+        counts.push_back((int)idx.size());
+        for (int i : idx) factors.push_back(i);
+    };
+    add_product(Fr::one(), {0, 1, 2});
+    auto append = [&](int b, const fe& lam) {
+        fe eta = lam;
+        add_product(lam, {b + 1});
+        eta = Fr::mul(eta, lam);
+        add_product(eta, {b, b + 1, b + 2});
+        add_product(Fr::neg(eta), {b, b + 3});  // degree_diff = 0: 2^-0 = 1
+        add_product(Fr::neg(lam), {b + 4});
+        eta = Fr::mul(eta, lam);
+        add_product(eta, {b, b + 4, b + 5});
+        add_product(Fr::neg(eta), {b});
+    };
+    append(3, lam_r);
+    append(9, lam_c);
+    std::vector<uint64_t> cabi = to_abi(coefs);
+    cozk_prodlist* pl = nullptr;
+    rc_check(cozk_prodlist_create(ctx, polys, 15, cabi.data(), counts.data(), factors.data(), coefs.size(), &pl), ctx, "prodlist_create");
+    struct PlGuard {
+        cozk_prodlist* p;
+        ~PlGuard() { cozk_prodlist_free(p); }
+    } plg{pl};
+    // distributed_sumcheck_worker (worker.rs:694-724)
+    std::vector<fe> point;
+    {
+        uint64_t rr[4];
+        for (int j = 0; j < qv; j++) {
+            uint64_t ev[16];
+            rc_check(cozk_prodlist_round(ctx, pl, j ? rr : nullptr, ev), ctx, "prodlist_round");
+            Writer w;
+            w.vec_fr({fe_from_u64x4(ev), fe_from_u64x4(ev + 4), fe_from_u64x4(ev + 8), fe_from_u64x4(ev + 12)});
+            star->send_response(w.b);
+            Bytes req = star->receive_request();
+            Reader rd(req);
+            fe r = rd.fr();
+            point.push_back(r);
+            fe_to_u64x4(r, rr);
+        }
+    }
+    fe eta;
+    {
+        Bytes req = star->receive_request();
+        Reader rd(req);
+        eta = rd.fr();
+    }
+    // distributed_batch_open_poly_worker (worker.rs:745-772): the 9 committed polynomials batched with powers of eta and opened
+    // at the sumcheck's point, the evaluations of all 15
+    {
+        const cozk_vec* all[15] = {lr[0].h, lr[2].h, lc[0].h, lc[2].h, erx.h, ery.h, ps.val_pad[0].h, ps.val_pad[1].h, ps.val_pad[2].h,
+                                   ps.freq_r.h, q_row.h, t_row.h, ps.freq_c.h, q_col.h, t_col.h};
+        std::vector<PolyH> ph;
+        std::vector<const cozk_poly*> pp;
+        for (int i = 0; i < 15; i++) {
+            cozk_poly* p = nullptr;
+            rc_check(cozk_poly_create(ctx, COZK_MODE_PLAIN, all[i], nullptr, &p), ctx, "poly_create");
+            ph.emplace_back(p);
+            pp.push_back(p);
+        }
+        std::vector<fe> pw(9);
+        pw[0] = Fr::one();
+        for (int i = 1; i < 9; i++) pw[i] = Fr::mul(pw[i - 1], eta);
+        std::vector<uint64_t> pabi = to_abi(pw);
+        cozk_poly* agg = nullptr;
+        rc_check(cozk_poly_linear_combination(ctx, pp.data(), pabi.data(), 9, COZK_MODE_PLAIN, 0, &agg), ctx, "aggregate_poly");
+        PolyH aggh(agg);
+        cozk_vec* av = nullptr;
+        rc_check(cozk_poly_share_view(ctx, agg, 0, &av), ctx, "share_view");
+        VecH aggv(av);
+        std::vector<g1_affine> pf = PST13::open(ctx, *ps.setup_idx, aggv.h, point);
+        VecH chi = eq_le_device(ctx, point);
+        std::vector<uint64_t> ev(4 * 15);
+        rc_check(cozk_poly_batch_evaluate_at_chi(ctx, pp.data(), 15, chi.h, ev.data()), ctx, "evaluations at the point");
+        std::vector<fe> evals(15);
+        for (int i = 0; i < 15; i++) evals[i] = fe_from_u64x4(ev.data() + 4 * i);
+        Writer w;
+        w.vec_g1(pf);
+        w.vec_fr(evals);
+        star->send_response(w.b);
+    }
 }
 
 // --------------------------------------------------------------------------- worker
@@ -305,6 +582,12 @@ static void spartan_worker_main(cozk_spartan* h, SpartanParty& ps, StarNetWorker
     }
     double t6 = now_ms();
     ps.t_open = t6 - t5;
+    if (c.lookup_round) {
+        spartan_lookup_worker(h, ps, star, rx, ry, coef);
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+        ps.t_lookup = now_ms() - t6;
+        t6 = now_ms();
+    }
     ps.t_total = t6 - t0;
     ps.star_up = star->bytes_up;
     ps.star_down = star->bytes_down;
@@ -393,6 +676,110 @@ static bool spartan_verify(cozk_spartan* h, const SpartanProof& pf, std::string&
         why = "PST13 opening check failed";
         return false;
     }
+    if (c.lookup_round) {
+        // LogLookupProof::verify (spartan/src/logup.rs:117-190) as verifier.rs:124-150 calls it: sumcheck from the claimed sum
+        // val_m, the final identity from the opened evaluations, the eta-batched opening under vk_index (with the trapdoor)
+        const int qv = h->qv;
+        const size_t NZ = (size_t)1 << qv, real = h->h_col.size();
+        if (!pf.has_lookup || pf.val_abc.size() != 3 || pf.h_comms.size() != 4 || (int)pf.lk_msgs.size() != qv || pf.lk_evals.size() != 15 ||
+            (int)pf.lk_opening.size() != qv) {
+            why = "lookup round: malformed proof";
+            return false;
+        }
+        if (!Fr::eq(pf.val_abc[0], ar) || !Fr::eq(pf.val_abc[1], br) || !Fr::eq(pf.val_abc[2], cr)) {
+            why = "lookup round: val_a, val_b, val_c != the second sumcheck's A, B, C(rx, ry)";
+            return false;
+        }
+        tr.append_scalars(pf.val_abc);
+        tr.append_point(pf.c_rx);
+        tr.append_point(pf.c_ry);
+        fe v = tr.challenge_scalar(), x[2];
+        x[0] = tr.challenge_scalar();
+        x[1] = tr.challenge_scalar();
+        for (const auto& cm : pf.h_comms) tr.append_point(cm);
+        std::vector<fe> z[2];
+        fe lam[2];
+        for (int i = 0; i < 2; i++) {
+            z[i] = tr.challenge_vector(qv);
+            lam[i] = tr.challenge_scalar();
+        }
+        fe expected = Fr::add(Fr::add(Fr::mul(abc[0], pf.val_abc[0]), Fr::mul(abc[1], pf.val_abc[1])), Fr::mul(abc[2], pf.val_abc[2]));
+        std::vector<fe> point;
+        for (int j = 0; j < qv; j++) {
+            const std::vector<fe>& ev = pf.lk_msgs[j];
+            if (ev.size() != 4 || !Fr::eq(Fr::add(ev[0], ev[1]), expected)) {
+                why = "lookup sumcheck: round " + std::to_string(j) + " g(0) + g(1) != claim";
+                return false;
+            }
+            tr.append_scalars(ev);
+            fe r = tr.challenge_scalar();
+            point.push_back(r);
+            expected = eval_points(ev, r);
+        }
+        fe eta = tr.challenge_scalar();
+        const std::vector<fe>& E = pf.lk_evals;
+        const fe one = Fr::one();
+        fe res = Fr::mul(Fr::mul(E[4], E[5]), Fr::add(Fr::add(Fr::mul(E[6], abc[0]), Fr::mul(E[7], abc[1])), Fr::mul(E[8], abc[2])));  // aux_eval
+        for (int i = 0; i < 2; i++) {
+            const fe &h0 = E[2 * i], &h1 = E[2 * i + 1], &m_e = E[9 + 3 * i], &q_e = E[10 + 3 * i], &t_e = E[11 + 3 * i];
+            fe eqv = eq_eval(point, z[i]);
+            fe l2 = Fr::mul(lam[i], lam[i]), l3 = Fr::mul(l2, lam[i]);
+            fe q0 = Fr::add(Fr::mul(h0, lam[i]), Fr::mul(Fr::mul(eqv, l2), Fr::sub(Fr::mul(h0, Fr::add(t_e, x[i])), m_e)));
+            fe q1 = Fr::add(Fr::neg(Fr::mul(h1, lam[i])), Fr::mul(Fr::mul(eqv, l3), Fr::sub(Fr::mul(h1, Fr::add(q_e, x[i])), one)));
+            res = Fr::add(res, Fr::add(q0, q1));
+        }
+        if (!Fr::eq(res, expected)) {
+            why = "lookup sumcheck: final evaluation mismatch";
+            return false;
+        }
+        // the six public polynomials at the point, recomputed (BatchOracleEval.debug_val is not trusted here)
+        {
+            std::vector<fe> ex = eq_table_le_host(rx), ey = eq_table_le_host(ry), chi = eq_table_le_host(point);
+            std::vector<fe> erx(NZ, Fr::zero()), ery(NZ, Fr::zero());
+            std::vector<uint32_t> fr_(NZ, 0), fc_(NZ, 0);
+            for (size_t e = 0; e < real; e++) {
+                erx[e] = ex[e / 3];
+                ery[e] = ey[h->h_col[e]];
+            }
+            for (size_t e = 0; e < NZ; e++) {
+                fr_[e < real ? e / 3 : 0]++;
+                fc_[e < real ? h->h_col[e] : h->h_col[0]]++;
+            }
+            auto idx_fe = [](size_t i) { return Fr::from_u64((uint64_t)i); };
+            fe pub[6] = {Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero(), Fr::zero()};
+            for (size_t e = 0; e < NZ; e++) {
+                size_t r_e = e < real ? e / 3 : 0, c_e = e < real ? h->h_col[e] : h->h_col[0];
+                fe qr = Fr::add(idx_fe(r_e), Fr::mul(v, erx[r_e])), qc = Fr::add(idx_fe(c_e), Fr::mul(v, ery[c_e]));
+                fe tr_ = Fr::add(idx_fe(e), Fr::mul(v, erx[e])), tc = Fr::add(idx_fe(e), Fr::mul(v, ery[e]));
+                pub[0] = Fr::add(pub[0], Fr::mul(Fr::from_u64(fr_[e]), chi[e]));
+                pub[1] = Fr::add(pub[1], Fr::mul(qr, chi[e]));
+                pub[2] = Fr::add(pub[2], Fr::mul(tr_, chi[e]));
+                pub[3] = Fr::add(pub[3], Fr::mul(Fr::from_u64(fc_[e]), chi[e]));
+                pub[4] = Fr::add(pub[4], Fr::mul(qc, chi[e]));
+                pub[5] = Fr::add(pub[5], Fr::mul(tc, chi[e]));
+            }
+            for (int i = 0; i < 6; i++)
+                if (!Fr::eq(pub[i], E[9 + i])) {
+                    why = "lookup round: public evaluation " + std::to_string(i) + " (freq / query / table) mismatch";
+                    return false;
+                }
+        }
+        // batch_verify_poly (verifier.rs:256-272)
+        std::vector<g1_affine> comms(pf.h_comms);
+        comms.push_back(pf.c_rx);
+        comms.push_back(pf.c_ry);
+        for (const auto& o : h->val_oracles) comms.push_back(o);
+        std::vector<fe> pw(9);
+        pw[0] = one;
+        for (int i = 1; i < 9; i++) pw[i] = Fr::mul(pw[i - 1], eta);
+        fe batch_eval = Fr::zero();
+        for (int i = 0; i < 9; i++) batch_eval = Fr::add(batch_eval, Fr::mul(pw[i], E[i]));
+        g1_affine batch_comm = PST13::combine_commitments(comms, pw);
+        if (!PST13::check_with_trapdoor(*h->parties[0].setup_idx, batch_comm, point, batch_eval, pf.lk_opening)) {
+            why = "lookup round: batched PST13 opening check failed";
+            return false;
+        }
+    }
     return true;
 }
 
@@ -480,6 +867,74 @@ static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, Sp
         pf.z_eval = Fr::add(pf.z_eval, rd.fr());
     }
     pf.opening = PST13::coordinate_prove(net);
+    if (c.lookup_round) {
+        // fourth_round, coordinator side (coordinator.rs:475-591) after third_round's public claims (:430-470)
+        const int qv = h->qv;
+        {
+            std::vector<Bytes> m = net.receive_responses();
+            Reader rd(m[0]);
+            pf.val_abc = rd.vec_fr();
+            pf.c_rx = rd.g1();
+            pf.c_ry = rd.g1();
+            if (pf.val_abc.size() != 3) throw CozkError(COZK_ERR_INTERNAL, "spartan: val_a, val_b, val_c expected");
+        }
+        tr.append_scalars(pf.val_abc);
+        tr.append_point(pf.c_rx);
+        tr.append_point(pf.c_ry);
+        {
+            fe v = tr.challenge_scalar(), x_r = tr.challenge_scalar(), x_c = tr.challenge_scalar();
+            Writer w;
+            w.fr(v);
+            w.fr(x_r);
+            w.fr(x_c);
+            net.broadcast_request(w.b);
+        }
+        {
+            std::vector<Bytes> m = net.receive_responses();
+            Reader rd(m[0]);
+            for (int i = 0; i < 4; i++) {
+                pf.h_comms.push_back(rd.g1());
+                tr.append_point(pf.h_comms.back());
+            }
+        }
+        {
+            std::vector<fe> z_r = tr.challenge_vector(qv);
+            fe lam_r = tr.challenge_scalar();
+            std::vector<fe> z_c = tr.challenge_vector(qv);
+            fe lam_c = tr.challenge_scalar();
+            Writer w;
+            w.vec_fr(z_r);
+            w.fr(lam_r);
+            w.vec_fr(z_c);
+            w.fr(lam_c);
+            net.broadcast_request(w.b);
+        }
+        for (int j = 0; j < qv; j++) {  // distributed_sumcheck_coordinator (coordinator.rs:748-811), one public worker
+            std::vector<Bytes> m = net.receive_responses();
+            Reader rd(m[0]);
+            std::vector<fe> ev = rd.vec_fr();
+            if (ev.size() != 4) throw CozkError(COZK_ERR_INTERNAL, "spartan: lookup sumcheck message length");
+            tr.append_scalars(ev);
+            fe r = tr.challenge_scalar();
+            pf.lk_msgs.push_back(ev);
+            Writer w;
+            w.fr(r);
+            net.broadcast_request(w.b);
+        }
+        {
+            fe eta = tr.challenge_scalar();
+            Writer w;
+            w.fr(eta);
+            net.broadcast_request(w.b);
+        }
+        {
+            std::vector<Bytes> m = net.receive_responses();
+            Reader rd(m[0]);
+            pf.lk_opening = rd.vec_g1();
+            pf.lk_evals = rd.vec_fr();
+        }
+        pf.has_lookup = true;
+    }
     if (!verify) return -1;
     return spartan_verify(h, pf, why) ? 1 : 0;
 }
@@ -498,6 +953,7 @@ int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out) {
         COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24, "spartan: log_n out of range");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->n = (size_t)1 << cfg->log_n;
+        h->qv = cfg->log_n + 2;  // 3 n entries padded to 4 n (indexer.rs:176-178)
         std::vector<fe> z_plain;
         spartan_build_instance(h, z_plain);
         h->parties.resize((size_t)h->nparties);
@@ -532,6 +988,9 @@ int cozk_spartan_destroy(cozk_spartan* h) {
         ps.z = PolyH();
         for (VecH* v : {&ps.row_ptr, &ps.col, &ps.va, &ps.vb, &ps.vc, &ps.t_ptr, &ps.t_row, &ps.t_va, &ps.t_vb, &ps.t_vc}) *v = VecH();
         ps.setup.reset();
+        for (VecH* v : {&ps.rows_u32, &ps.cols_u32, &ps.domain_u32, &ps.val_pad[0], &ps.val_pad[1], &ps.val_pad[2], &ps.freq_r, &ps.freq_c}) *v = VecH();
+        for (int k = 0; k < 3; k++) ps.val_poly[k] = PolyH();
+        ps.setup_idx.reset();
         if (ps.own_ctx && ps.ctx) cozk_ctx_destroy(ps.ctx);
     }
     delete h;
@@ -595,6 +1054,7 @@ int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res) {
         res->t_sumcheck2_ms = std::max(res->t_sumcheck2_ms, ps.t_sc2);
         res->t_open_ms = std::max(res->t_open_ms, ps.t_open);
         res->t_worker_ms = std::max(res->t_worker_ms, ps.t_total);
+        res->t_lookup_ms = std::max(res->t_lookup_ms, ps.t_lookup);
         res->bytes_star_up += ps.star_up;
         res->bytes_star_down += ps.star_down;
         res->star_messages += ps.star_msgs;

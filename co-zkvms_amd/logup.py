@@ -7,13 +7,15 @@ import numpy as np
 from . import _lib as L
 from .engine import Vec, fr_to_mont_limbs, mont_limbs_to_int
 
-LOGUP_SYMBOLS = ["cozk_hash_tuple", "cozk_logup_h", "cozk_vec_boost_degree", "cozk_prodlist_create", "cozk_prodlist_free", "cozk_prodlist_degree",
+LOGUP_SYMBOLS = ["cozk_vec_gather", "cozk_hash_tuple", "cozk_logup_h", "cozk_vec_boost_degree", "cozk_prodlist_create", "cozk_prodlist_free", "cozk_prodlist_degree",
                  "cozk_prodlist_round", "cozk_prodlist_final"]
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
 
 def _decl():
     l = L.lib()
+    l.cozk_vec_gather.restype = _i
+    l.cozk_vec_gather.argtypes = [_vp, _vp, _vp, _sz, ctypes.POINTER(_vp)]
     l.cozk_hash_tuple.restype = _i
     l.cozk_hash_tuple.argtypes = [_vp, _vp, _vp, _vp, _sz, ctypes.POINTER(_vp)]
     l.cozk_logup_h.restype = _i
@@ -31,6 +33,15 @@ def _decl():
     l.cozk_prodlist_final.restype = _i
     l.cozk_prodlist_final.argtypes = [_vp, _vp, _vp, _vp]
     return l
+
+
+def gather(ctx, idx, src, n_out):
+    """eq_tilde_{rx,ry}: out[j] = src[idx[j]] (0xffffffff: no entry -> 0), zero padding up to n_out"""
+    l = _decl()
+    iv = Vec.from_ints(ctx, idx, kind=L.SCALAR_U32)
+    h = _vp()
+    ctx.check(l.cozk_vec_gather(ctx.h, iv.h, src.h, n_out, ctypes.byref(h)))
+    return Vec(ctx, h, L.SCALAR_FR)
 
 
 def hash_tuple(ctx, idx, eq, v_msg, n_out):

@@ -444,6 +444,9 @@ int cozk_outer_final_evals(cozk_ctx* ctx, cozk_outer* st, const uint64_t r[4], u
  * (a power of two) repeats entry 0 */
 int cozk_hash_tuple(cozk_ctx* ctx, const cozk_vec* idx_u32, const cozk_vec* eq, const uint64_t v_msg[4], size_t n_out,
                     cozk_vec** out);
+/* eq_tilde_{rx,ry}(_chunk) of third_round (worker.rs:296-343,376-391): out[j] = src[idx[j]] (0xffffffff = usize::MAX and the
+ * padding up to n_out: 0) */
+int cozk_vec_gather(cozk_ctx* ctx, const cozk_vec* idx_u32, const cozk_vec* src, size_t n_out, cozk_vec** out);
 /* LogLookupProof::prove's field work (logup.rs:45-70): phi = x + values, h = m / phi (m = NULL: 1 / phi) */
 int cozk_logup_h(cozk_ctx* ctx, const cozk_vec* values, const cozk_vec* m, const uint64_t x[4], cozk_vec** out_phi,
                  cozk_vec** out_h);
@@ -646,6 +649,10 @@ typedef struct cozk_spartan_config {
     int precompute; /* window table for the SRS (as cozk_harness_config) */
     int devices[3];
     uint64_t seed;
+    int lookup_round; /* 1: also the PUBLIC part of the protocol with one public worker (party 0's GPU):
+                       * third_round's tail (worker.rs:296-343: val_a, val_b, val_c, commitments of eq_tilde_rx / ry) and
+                       * fourth_round (worker.rs:398-575: two logup lookups, distributed sumcheck, batch opening of 15
+                       * polynomials under ck_index); its proof part is appended and verified (spartan/src/logup.rs:117-190) */
 } cozk_spartan_config;
 typedef struct cozk_spartan_result {
     int verified; /* 1 ok, 0 rejected, -1 not run */
@@ -654,6 +661,7 @@ typedef struct cozk_spartan_result {
     uint64_t bytes_star_up, bytes_star_down, star_messages;
     uint64_t proof_len;
     uint8_t proof_digest[32]; /* SHA-256 of the serialized proof */
+    double t_lookup_ms;       /* cfg.lookup_round: the public worker's third-round tail + fourth round */
 } cozk_spartan_result;
 int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out);
 const char* cozk_spartan_error(const cozk_spartan* h);

@@ -9,6 +9,19 @@ agreeing bit for bit with the independent HIP implementation.
 
 Reference call chain restated: co-noir-spartan/co-spartan/src/worker.rs:119-300 (zero_round, first_round,
 second_round, third_round), sumcheck.rs:171-395 (round functions), worker.rs:774-809 (distributed_open).
+
+cfg["lookup_round"] = 1 adds the PUBLIC part of the protocol, run by one public worker (log_num_public_workers
+= 0: start_eq = 0, log_chunk_size = num_variables_val, degree_diff = 0):
+  third_round's public tail     worker.rs:296-343 (val_a, val_b, val_c = sum val * eq_rx[row] * eq_ry[col]; commitments of
+                                eq_tilde_rx_chunk, eq_tilde_ry_chunk under ck_index; val_m = v . (val_a, val_b, val_c) polys)
+  fourth_round                  worker.rs:398-575 (hash_tuple queries / tables, two LogLookupProof::prove, append_sumcheck_polys,
+                                distributed_sumcheck_worker, distributed_batch_open_poly_worker of 15 polynomials / 9 commitments),
+                                coordinator.rs:475-591, verification spartan/src/logup.rs:117-190 + verifier.rs:124-150,256-272
+  index                         spartan/src/indexer.rs:176-231 (entries padded to a power of two, rows / cols padded with the first
+                                term, normalized_multiplicities, ck_index with num_variables_val variables, val_{a,b,c} oracles)
+Kept as the reference has it: hash_tuple indexes eq_tilde_rx (a per-ENTRY table) with ROW / COLUMN values (worker.rs:418-428,
+the comment there says so); the lookup argument is sound for the table it is given.  Not kept: the verifier recomputes the six
+public evaluations (freq, query, table) itself instead of trusting BatchOracleEval.debug_val.
 """
 import hashlib
 
@@ -153,4 +166,118 @@ def run(cfg):
     blob += _ser_u64(len(sc1)) + b"".join(_ser_vec(e) for e in sc1) + _ser_vec(fin1)
     blob += _ser_u64(len(sc2)) + b"".join(_ser_vec(e) for e in sc2) + _ser_vec(fin2)
     blob += _ser_fr(z_eval) + _ser_u64(len(proofs)) + b"".join(_ser_g1(p) for p in proofs)
+    if cfg.get("lookup_round"):
+        lk_blob, lk_ok = lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr)
+        blob += lk_blob
+        ok &= lk_ok
     return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": bool(ok)}
+
+
+def index_ck(seed, qv):
+    """ck_index (indexer.rs:184): a PST13 key with num_variables_val variables; trapdoor derived from the seed"""
+    t = O.synthetic_fr(seed ^ 0x1D1D1D1D, qv)
+    powers = []
+    for i in range(qv):
+        ev = [1]
+        for tj in t[i:]:
+            ev = [e * (1 - tj) % R for e in ev] + [e * tj % R for e in ev]
+        powers.append([O.g1_mul(O.G1_GEN, e) for e in ev])
+    return {"nv": qv, "t": t, "g": O.G1_GEN, "powers_of_g": powers}
+
+
+def multiplicities(idx, size):
+    """normalized_multiplicities (spartan/src/utils.rs:128-172) of the padded index vector against the domain 0 .. size - 1
+    (every domain value occurs once in the table, so the normalisation divides by one)"""
+    m = [0] * size
+    for i in idx:
+        m[i] += 1
+    return m
+
+
+def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
+    """third_round's public tail + fourth_round with one public worker; returns (proof bytes, verified)"""
+    import pylogup as G
+    n = 1 << nv
+    real = len(entries)
+    qv = max(1, (real - 1).bit_length())
+    NZ = 1 << qv
+    rows = [e[0] for e in entries]
+    cols = [e[1] for e in entries]
+    pad = lambda v: list(v) + [0] * (NZ - len(v))
+    val_a, val_b, val_c = pad([e[2] for e in entries]), pad([e[3] for e in entries]), pad([e[4] for e in entries])
+    ck = index_ck(seed, qv)
+    val_oracles = [O.pst_commit(ck, v) for v in (val_a, val_b, val_c)]  # IndexVerifierKey (indexer.rs:205-207)
+    ok = True
+    # ---- third_round, public tail (worker.rs:296-343)
+    erx = pad([eq_rx[r] for r in rows])  # eq_tilde_rx_chunk = eq_tilde_rx for the single public worker
+    ery = pad([eq_ry[c] for c in cols])
+    val_abc = [sum(v[e] * erx[e] % R * ery[e] for e in range(real)) % R for v in (val_a, val_b, val_c)]
+    c_rx, c_ry = O.pst_commit(ck, erx), O.pst_commit(ck, ery)
+    tr.append_scalars(val_abc)
+    tr.append_point(c_rx)
+    tr.append_point(c_ry)
+    ok &= val_abc == [fin2[1], fin2[2], fin2[3]]  # the second sumcheck's A, B, C(rx, ry) claims
+    val_m = [(abc[0] * a + abc[1] * b + abc[2] * c) % R for a, b, c in zip(val_a, val_b, val_c)]
+    # ---- fourth_round (worker.rs:398-575, coordinator.rs:475-591)
+    v = tr.challenge_scalar()
+    q_row = G.hash_tuple(rows, erx, v)
+    q_col = G.hash_tuple(cols, ery, v)
+    t_row = G.hash_tuple(list(range(NZ)), erx, v)
+    t_col = G.hash_tuple(list(range(NZ)), ery, v)
+    assert len(q_row) == NZ and len(q_col) == NZ
+    freq_r = multiplicities(rows + [rows[0]] * (NZ - real), NZ)  # pad_with_first_term (indexer.rs:212-217)
+    freq_c = multiplicities(cols + [cols[0]] * (NZ - real), NZ)
+    x_r = tr.challenge_scalar()
+    x_c = tr.challenge_scalar()
+    h_r, phi_r = G.loglookup_prove(q_row, t_row, freq_r, x_r)
+    h_c, phi_c = G.loglookup_prove(q_col, t_col, freq_c, x_c)
+    comms = [O.pst_commit(ck, p) for p in (h_r[0], h_r[1], h_c[0], h_c[1])]
+    for c in comms:
+        tr.append_point(c)
+    z_r = tr.challenge_vector(qv)
+    lam_r = tr.challenge_scalar()
+    z_c = tr.challenge_vector(qv)
+    lam_c = tr.challenge_scalar()
+    polys, products = [erx, ery, val_m], [(1, [0, 1, 2])]
+    G.append_sumcheck_polys(polys, products, h_r, phi_r, freq_r, 0, z_r, lam_r)
+    G.append_sumcheck_polys(polys, products, h_c, phi_c, freq_c, 0, z_c, lam_c)
+    msgs, point, _finals = G.distributed_sumcheck(polys, products, tr)
+    eta = tr.challenge_scalar()
+    committed = [h_r[0], h_r[1], h_c[0], h_c[1], erx, ery, val_a, val_b, val_c]
+    public = [freq_r, q_row, t_row, freq_c, q_col, t_col]
+    agg = [0] * NZ
+    w = 1
+    for p in committed:
+        agg = [(a + w * b) % R for a, b in zip(agg, p)]
+        w = w * eta % R
+    proofs, val = O.pst_open(ck, agg, point)
+    evals = [O.pst_evaluate_le(p, point) for p in committed + public]
+    # ---- verification (logup.rs:117-190, verifier.rs:124-150): sumcheck from the claimed sum val_m, final identity, batch opening
+    expected = (abc[0] * val_abc[0] + abc[1] * val_abc[1] + abc[2] * val_abc[2]) % R
+    for ev, r in zip(msgs, point):
+        ok &= len(ev) == 4 and (ev[0] + ev[1]) % R == expected
+        expected = G.interpolate_uni(ev, r)
+    res = evals[4] * evals[5] % R * ((evals[6] * abc[0] + evals[7] * abc[1] + evals[8] * abc[2]) % R) % R  # aux_eval
+    for i, (x, z, lam) in enumerate(((x_r, z_r, lam_r), (x_c, z_c, lam_c))):
+        h0, h1 = evals[2 * i], evals[2 * i + 1]
+        m_e, q_e, t_e = evals[9 + 3 * i], evals[10 + 3 * i], evals[11 + 3 * i]
+        eqv = 1
+        for a, b in zip(point, z):
+            eqv = eqv * ((a * b + (1 - a) * (1 - b)) % R) % R
+        q0 = (h0 * lam + eqv * lam % R * lam % R * ((h0 * (t_e + x) - m_e) % R)) % R
+        q1 = (-h1 * lam + eqv * pow(lam, 3, R) % R * ((h1 * (q_e + x) - 1) % R)) % R
+        res = (res + q0 + q1) % R
+    ok &= res == expected
+    all_comms = comms + [c_rx, c_ry] + val_oracles
+    batch_comm, batch_eval, w = None, 0, 1
+    for c, e in zip(all_comms, evals[:9]):
+        term = O.g1_mul(c, w)
+        batch_comm = term if batch_comm is None else O.g1_add(batch_comm, term)
+        batch_eval = (batch_eval + w * e) % R
+        w = w * eta % R
+    ok &= val == batch_eval
+    ok &= O.pst_check_with_trapdoor(ck, batch_comm, point, batch_eval, proofs)
+    blob = _ser_vec(val_abc) + _ser_g1(c_rx) + _ser_g1(c_ry) + b"".join(_ser_g1(c) for c in comms)
+    blob += _ser_u64(len(msgs)) + b"".join(_ser_vec(e) for e in msgs)
+    blob += _ser_vec(evals) + _ser_u64(len(proofs)) + b"".join(_ser_g1(p) for p in proofs)
+    return blob, bool(ok)

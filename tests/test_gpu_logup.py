@@ -24,6 +24,8 @@ def test_hash_tuple_logup_h_and_boost_degree(cozk, ctx):
     v = rng.field()
     got = LG.hash_tuple(ctx, idx, cozk.Vec.from_ints(ctx, eq), v, 64).to_ints()
     assert got == G.hash_tuple(idx, eq, v)
+    gidx = idx + [0xFFFFFFFF, 3]
+    assert LG.gather(ctx, gidx, cozk.Vec.from_ints(ctx, eq), 64).to_ints() == [eq[i] for i in idx] + [0, eq[3]] + [0] * (64 - len(gidx))
     vals = [rng.field() for _ in range(100)] + [0, 1, R - 1]
     m = [rng.next() % 5 for _ in range(len(vals))]
     x = rng.field()

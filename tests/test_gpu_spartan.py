@@ -54,3 +54,35 @@ def test_config4_2p18_plain_verifies(cozk):
     assert r.verified == 1, h.last_error()
     assert r.proof_len == 8 + 64 + 8 + 18 * (8 + 4 * 32) + (8 + 4 * 32) + 8 + 18 * (8 + 3 * 32) + (8 + 4 * 32) + 32 + 8 + 18 * 64
     h.close()
+
+
+@pytest.mark.parametrize("mode", ["plain", "rep3"])
+@pytest.mark.parametrize("log_n,seed", [(2, 3), (3, 5), (5, 7)])
+def test_lookup_round_proof_bit_identical_to_oracle(cozk, mode, log_n, seed):
+    """SURVEY 8(f)4 wired end to end: third_round's public tail + fourth_round (co-noir-spartan/co-spartan/src/worker.rs:296-343,
+    398-575) with one public worker on the GPU -- hash_tuple queries / tables, two LogLookupProof::prove, the 13-product
+    distributed sumcheck, the eta-batched opening of 9 commitments + 15 evaluations under ck_index -- verified as
+    spartan/src/logup.rs:117-190 does, and byte-identical to oracle/pyspartan.py's lookup_round"""
+    h = cozk.SpartanHarness(mode=mode, log_n=log_n, seed=seed, lookup_round=True)
+    res = h.prove(verify=True)
+    assert res.verified == 1, h.last_error()
+    ref = pyspartan.run(dict(log_n=log_n, seed=seed, lookup_round=1))
+    assert ref["verified"]
+    got = h.proof_bytes(res)
+    assert got == ref["proof_bytes"]
+    base = pyspartan.run(dict(log_n=log_n, seed=seed))
+    assert got[:len(base["proof_bytes"])] == base["proof_bytes"] and len(got) > len(base["proof_bytes"])
+    h.close()
+
+
+def test_lookup_round_2p14_verifies_and_rep3_equals_plain(cozk):
+    digs = []
+    for mode in ("plain", "rep3"):
+        h = cozk.SpartanHarness(mode=mode, log_n=14, seed=2026, lookup_round=True)
+        r1 = h.prove(verify=True)
+        assert r1.verified == 1, h.last_error()
+        assert r1.t_lookup_ms > 0
+        assert _digest(h.prove(verify=False)) == _digest(r1)
+        digs.append(_digest(r1))
+        h.close()
+    assert digs[0] == digs[1]
