@@ -184,22 +184,22 @@ struct MsmPolyDesc {
     uint32_t group;     // bucket group (= polynomial index inside the launch set)
     uint32_t pad;
 };
-static constexpr int LTPB = 1024;
+static constexpr int LTPB = 1024;  // launch bound of the LDS-histogram kernels; the launch width is chosen in msm_sort
 
 template <int KIND>
 __global__ void __launch_bounds__(LTPB) k_msm_hist_lds(const MsmPolyDesc* __restrict__ descs, uint32_t* __restrict__ hist) {
     __shared__ uint32_t lh[NB];
     const MsmPolyDesc d = descs[blockIdx.y];
-    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lh[b] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (size_t)gridDim.x * blockDim.x) {
         for_each_digit<KIND>(d.scalars, i, [&](int, uint32_t mag, bool) {
             if (mag != 0) atomicAdd(&lh[mag - 1u], 1u);
         });
     }
     __syncthreads();
     uint32_t* h = hist + (size_t)d.group * NB;
-    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) {
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) {
         uint32_t c = lh[b];
         if (c) atomicAdd(&h[b], c);
     }
@@ -210,21 +210,21 @@ __global__ void __launch_bounds__(LTPB) k_msm_scatter_lds(const MsmPolyDesc* __r
                                                        uint32_t* __restrict__ refs, uint32_t table_n) {
     __shared__ uint32_t lh[NB];
     const MsmPolyDesc d = descs[blockIdx.y];
-    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) lh[b] = 0;
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) lh[b] = 0;
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (size_t)gridDim.x * blockDim.x) {
         for_each_digit<KIND>(d.scalars, i, [&](int, uint32_t mag, bool) {
             if (mag != 0) atomicAdd(&lh[mag - 1u], 1u);
         });
     }
     __syncthreads();
     uint32_t* cur = cursor + (size_t)d.group * NB;
-    for (uint32_t b = threadIdx.x; b < NB; b += LTPB) {
+    for (uint32_t b = threadIdx.x; b < NB; b += blockDim.x) {
         uint32_t c = lh[b];
         lh[b] = c ? atomicAdd(&cur[b], c) : 0u;  // this workgroup's slot range inside bucket b
     }
     __syncthreads();
-    for (size_t i = (size_t)blockIdx.x * LTPB + threadIdx.x; i < d.n; i += (size_t)gridDim.x * LTPB) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < d.n; i += (size_t)gridDim.x * blockDim.x) {
         for_each_digit<KIND>(d.scalars, i, [&](int k, uint32_t mag, bool negative) {
             if (mag != 0) {
                 uint32_t pos = atomicAdd(&lh[mag - 1u], 1u);
@@ -814,12 +814,18 @@ static void msm_sort(cozk_ctx* ctx, hipStream_t st, MsmSortWs& sw, const MsmSetP
             if (nd > first) runs.push_back({kind, {first, nd - first}});
         }
         HIP_TRY(hipMemcpyAsync(d_descs, h_descs, nd * sizeof(MsmPolyDesc), hipMemcpyHostToDevice, st));
+        // 256-thread workgroups (one wave per SIMD, 128 KiB of LDS each): narrow enough to slip into the CU slots that free
+        // up under the register-heavy gather kernel of the previous launch set, so the sort really runs beside it (wider
+        // workgroups wait for the gather's grid to drain: measured 127.8 -> 123.5 ms per proof at 2^20, same box)
+        static const int ltpb = getenv("COZK_MSM_LTPB") ? atoi(getenv("COZK_MSM_LTPB")) : 256;
+        static const uint32_t wgs_max = getenv("COZK_MSM_WGS") ? (uint32_t)atoi(getenv("COZK_MSM_WGS")) : 64u;
+        COZK_REQUIRE(ltpb >= 64 && ltpb <= LTPB && ltpb % 64 == 0, "COZK_MSM_LTPB out of range");
         uint32_t wgs = (uint32_t)((max_n + 4095) / 4096);  // >= 4096 scalars per workgroup (measured: 64 beats 16 workgroups 2x)
         if (wgs < 1) wgs = 1;
-        if (wgs > 64) wgs = 64;
+        if (wgs > wgs_max) wgs = wgs_max;
         for (auto& r : runs) {
             dim3 grid(wgs, r.second.second);
-            KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist)));
+            KIND_DISPATCH(r.first, (k_msm_hist_lds<K><<<grid, ltpb, 0, st>>>(d_descs + r.second.first, hist)));
         }
         read_back_max();
         msm_scan(st, bsums, nb, false, hist, 1, off0, hist);  // hist doubles as the scatter cursor after the scan
@@ -833,7 +839,7 @@ static void msm_sort(cozk_ctx* ctx, hipStream_t st, MsmSortWs& sw, const MsmSetP
                 alg += (uint64_t)d.n * (sb + 4ull * ((sb * 8 + 15) / 16));
             }
             ProfScope prof(ctx, COZK_PROF_MSM_SCATTER, alg, st);
-            KIND_DISPATCH(r.first, (k_msm_scatter_lds<K><<<grid, LTPB, 0, st>>>(d_descs + r.second.first, hist, refs, (uint32_t)bases->n)));
+            KIND_DISPATCH(r.first, (k_msm_scatter_lds<K><<<grid, ltpb, 0, st>>>(d_descs + r.second.first, hist, refs, (uint32_t)bases->n)));
         }
     } else {
         for (size_t p = 0; p < P; p++) {
@@ -1021,7 +1027,15 @@ void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, co
         static const bool pipeline = getenv("COZK_MSM_SERIAL") == nullptr;
         hipStream_t side = st;
         if (pipeline && sets.size() > 1) {
-            if (!ctx->stream2) HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            if (!ctx->stream2) {
+                // the sort stream outranks the main stream: its memory-bound workgroups take the CU slots that free up
+                // under the ALU-bound gather kernel instead of queueing behind that kernel's own next workgroups
+                static const bool prio = getenv("COZK_MSM_NO_PRIORITY") == nullptr;
+                int lo = 0, hi = 0;
+                HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));
+                if (prio) HIP_TRY(hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, hi));
+                else HIP_TRY(hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking));
+            }
             side = ctx->stream2;
         }
         for (int b = 0; b < 2; b++) {
