@@ -510,7 +510,7 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0(const g1_affine* __restrict_
 // The same gather in 9 x 29-bit unsaturated limbs (fq9.hip.hpp): no carry instructions in the products, no
 // conditional subtractions anywhere.  A segment that meets P == +-Q (repeated SRS points, cancelling digits) is
 // queued in `exc` ([0] = count, [1..] = segment ids) and redone by k_msm_accum0_fix with the saturated formulas.
-template <bool CHECK_INF>
+template <bool CHECK_INF, bool PF = false>
 __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restrict__ table, const uint32_t* __restrict__ refs,
                                                     const uint32_t* __restrict__ off_in, const uint32_t* __restrict__ off_out,
                                                     uint32_t nb, g1_xyzz* __restrict__ out, uint32_t* __restrict__ exc,
@@ -523,8 +523,10 @@ __global__ void __launch_bounds__(TPB) k_msm_accum0_f9(const g1_affine* __restri
     segment_range_perm(off_in, off_out, offp, perm, nb, t, blk, begin, end, slot);
     xyzz9 acc;
     bool have = false;
+    uint32_t ref_next = PF && begin < end ? refs[begin] : 0u;
     for (uint32_t e = begin; e < end; e++) {
-        uint32_t ref = refs[e];
+        uint32_t ref = PF ? ref_next : refs[e];
+        if (PF && e + 1 < end) ref_next = refs[e + 1];  // one iteration ahead: the point gather no longer waits for its index
         g1_affine p = affine_load(table + (ref & 0x7fffffffu));
         if (CHECK_INF && G1::is_inf(p)) continue;  // tables without a point at infinity (the usual SRS) skip the test
         f9 qx = f9_from_fe(p.x), qy = f9_from_fe(p.y);
@@ -907,8 +909,8 @@ static void msm_accumulate(cozk_ctx* ctx, MsmSortWs& sw, const MsmSetPlan& pl, c
         k_block_buckets<<<cdiv(nblk0 + 1, 256), 256, 0, st>>>(offP, nb, nblk0, blk);
         if (bases->has_inf)
             k_msm_accum0_f9<true><<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
-        else
-            k_msm_accum0_f9<false><<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
+        else  // index prefetch on (same-box A/B: -0.4 ms per proof, one more VGPR)
+            k_msm_accum0_f9<false, true><<<nblk0, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, blk, offP, perm);
         k_msm_accum0_fix<<<256, TPB, 0, st>>>(bases->table, refs, off0, offA, nb, ws.partA.as<g1_xyzz>(), exc, offP, perm);
     } else {
         k_msm_accum0<<<cdiv(maxseg0, TPB), TPB, 0, st>>>(bases->table, refs, off0, offA, nb, L0, ws.partA.as<g1_xyzz>());
