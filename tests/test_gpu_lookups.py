@@ -188,3 +188,32 @@ def test_primary_sumcheck_split_2p14_equals_unsplit(cozk):
         digs.append(bytes(r.proof_digest))
         h.close()
     assert digs[0] == digs[1]
+
+
+def test_hip_pipelines_reproduce_the_committed_golden_digests(cozk):
+    """tests/golden/round2_pipelines.json: the HIP harnesses give the committed digests of the lookups, spartan (+ public lookup
+    round) and outer-sumcheck pipelines"""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round2_pipelines.json")))
+    LK = importlib.import_module("co-zkvms_amd.lookups")
+    OU = importlib.import_module("co-zkvms_amd.outer")
+    for row in G["lookups"]:
+        cfg = dict(row["cfg"])
+        h = LK.LookupsHarness(mode=cfg.pop("mode"), primary=bool(cfg.pop("primary", 0)), **cfg)
+        r = h.prove(verify=True)
+        assert r.verified == 1 and bytes(r.proof_digest).hex() == row["digest"] and r.proof_len == row["proof_len"], row["cfg"]
+        h.close()
+    for row in G["spartan"]:
+        cfg = dict(row["cfg"])
+        for mode in ("plain", "rep3"):
+            h = cozk.SpartanHarness(mode=mode, log_n=cfg["log_n"], seed=cfg["seed"], lookup_round=bool(cfg.get("lookup_round", 0)))
+            r = h.prove(verify=True)
+            assert r.verified == 1 and bytes(r.proof_digest).hex() == row["digest"], (row["cfg"], mode)
+            h.close()
+    for row in G["outer"]:
+        cfg = dict(row["cfg"])
+        h = OU.OuterHarness(mode=cfg["mode"], log_steps=cfg["log_steps"], seed=cfg["seed"])
+        r = h.prove(verify=True)
+        assert r.verified == 1 and bytes(r.proof_digest).hex() == row["digest"], row["cfg"]
+        h.close()
