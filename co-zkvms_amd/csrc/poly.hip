@@ -72,19 +72,34 @@ __global__ void __launch_bounds__(PT) k_poly_bind(const fe* __restrict__ ia, con
 // (evaluate_at_chi, dense_mlpoly.rs:160-181; TWO_INV folded in by the finishing kernel)
 template <int NC>
 __global__ void __launch_bounds__(PT) k_poly_eval_chi(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
-                                                   const size_t* __restrict__ lens, const fe* __restrict__ chi,
+                                                   const size_t* __restrict__ lens, const fe* __restrict__ chi, int k,
                                                    fe* __restrict__ partial) {
     __shared__ fe sh4[4];
-    const fe* a = pa[blockIdx.y];
-    const fe* b = NC == 2 ? pb[blockIdx.y] : nullptr;
-    size_t n = lens[blockIdx.y];
-    fe acc = Fr::zero();
+    // a workgroup row serves TWO polynomials, so chi[i] is fetched once per pair (chi is 32 MiB at 2^20: it does not stay in
+    // L2 between the polynomials' passes); each product goes into its polynomial's wide accumulator (poly.hip.hpp: lazy dot
+    // products, one reduction per lane at the end)
+    const int p0 = 2 * blockIdx.y, p1 = p0 + 1;
+    const bool two = p1 < k;
+    const fe* a0 = pa[p0];
+    const fe* b0 = NC == 2 ? pb[p0] : nullptr;
+    const fe* a1 = two ? pa[p1] : nullptr;
+    const fe* b1 = (two && NC == 2) ? pb[p1] : nullptr;
+    const size_t n0 = lens[p0], n1 = two ? lens[p1] : 0;
+    const size_t n = n0 > n1 ? n0 : n1;
+    FrWide w0, w1;
+    fr_wide_zero(w0);
+    fr_wide_zero(w1);
     for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < n; i += (size_t)gridDim.x * PT) {
-        Sh<NC> s = sh_load<NC>(a, b, i);
-        acc = Fr::add(acc, Fr::mul(sh_ab_sum<NC>(s), fe_load(chi + i)));
+        fe c = fe_load(chi + i);
+        if (i < n0) fr_wide_mac(w0, sh_ab_sum<NC>(sh_load<NC>(a0, b0, i)), c);
+        if (i < n1) fr_wide_mac(w1, sh_ab_sum<NC>(sh_load<NC>(a1, b1, i)), c);
     }
-    acc = fr_block_sum(acc, sh4);
-    if (threadIdx.x == 0) fe_store(partial + (size_t)blockIdx.y * gridDim.x + blockIdx.x, acc);
+    fe acc = fr_block_sum(fr_wide_reduce(w0), sh4);
+    if (threadIdx.x == 0) fe_store(partial + (size_t)p0 * gridDim.x + blockIdx.x, acc);
+    if (two) {  // uniform per workgroup
+        acc = fr_block_sum(fr_wide_reduce(w1), sh4);
+        if (threadIdx.x == 0) fe_store(partial + (size_t)p1 * gridDim.x + blockIdx.x, acc);
+    }
 }
 
 // out[y] = scale * sum_x partial[y * nper + x]
@@ -102,15 +117,18 @@ template <int NC>
 __global__ void __launch_bounds__(PT) k_poly_dot_public(const fe* __restrict__ a, const fe* __restrict__ b,
                                                      const fe* __restrict__ pub, size_t n, fe* __restrict__ partial) {
     __shared__ fe sh4[4];
-    fe acc[NC];
-    for (int k = 0; k < NC; k++) acc[k] = Fr::zero();
+    FrWide w[NC];
+#pragma unroll
+    for (int k = 0; k < NC; k++) fr_wide_zero(w[k]);
     for (size_t i = (size_t)blockIdx.x * PT + threadIdx.x; i < n; i += (size_t)gridDim.x * PT) {
         Sh<NC> s = sh_load<NC>(a, b, i);
         fe p = fe_load(pub + i);
-        for (int k = 0; k < NC; k++) acc[k] = Fr::add(acc[k], Fr::mul(s.c[k], p));
+#pragma unroll
+        for (int k = 0; k < NC; k++) fr_wide_mac(w[k], s.c[k], p);
     }
+#pragma unroll
     for (int k = 0; k < NC; k++) {
-        fe v = fr_block_sum(acc[k], sh4);
+        fe v = fr_block_sum(fr_wide_reduce(w[k]), sh4);
         if (threadIdx.x == 0) fe_store(partial + (size_t)k * gridDim.x + blockIdx.x, v);
     }
 }
@@ -124,6 +142,23 @@ __global__ void __launch_bounds__(PT) k_poly_lincomb(const fe* const* __restrict
     size_t i = (size_t)blockIdx.x * PT + threadIdx.x;
     if (i >= n) return;
     Sh<NC> acc;
+    if (k >= 8) {
+        // long combinations (the rho-RLC of all committed polynomials): one reduction per output element instead of k
+        FrWide w[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) fr_wide_zero(w[c]);
+        for (int j = 0; j < k; j++) {
+            if (i < lens[j]) {
+                fe cf = fe_load(coeffs + j);
+                if (pa[j]) fr_wide_mac(w[0], fe_load(pa[j] + i), cf);
+                if (NC == 2 && pb[j]) fr_wide_mac(w[NC - 1], fe_load(pb[j] + i), cf);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc.c[c] = fr_wide_reduce(w[c]);
+        sh_store<NC>(oa, ob, i, acc);
+        return;
+    }
     for (int c = 0; c < NC; c++) acc.c[c] = Fr::zero();
     for (int j = 0; j < k; j++) {
         if (i < lens[j]) {
@@ -1224,7 +1259,10 @@ int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys
             if (hl[i] > maxlen) maxlen = hl[i];
         }
         unsigned gx = grid_capped(maxlen);
-        if (gx > 512) gx = 512;
+        // few, long lanes: a lane ends with one wide reduction per accumulator (8 products) + the block sums, which would outweigh
+        // its multiply-add chains if it only had a handful of elements (env COZK_EVAL_GX for A/B runs)
+        static const unsigned gx_cap = getenv("COZK_EVAL_GX") ? (unsigned)atoi(getenv("COZK_EVAL_GX")) : 192u;
+        if (gx > gx_cap) gx = gx_cap;
         size_t meta = k * (2 * sizeof(void*) + sizeof(size_t));
         ctx->scratch.reserve(meta + (k * gx + k) * sizeof(fe) + 64);
         char* base = (char*)ctx->scratch.p;
@@ -1237,14 +1275,14 @@ int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys
         HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipStreamSynchronize(ctx->stream));  // host vectors go out of scope
-        dim3 grid(gx, (unsigned)k);
+        dim3 grid(gx, (unsigned)((k + 1) / 2));
         {
             // algorithmic bytes: chi read once for the batch, every polynomial once (96 n, then 64 n per extra polynomial: SURVEY 8d K6)
             uint64_t alg = (uint64_t)chi->n * 32;
             for (size_t i = 0; i < k; i++) alg += (uint64_t)hl[i] * (mode == COZK_MODE_REP3 ? 64 : 32);
             ProfScope prof(ctx, COZK_PROF_EVAL_CHI, alg);
-            if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
-            else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, partial);
+            if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, (int)k, partial);
+            else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, (int)k, partial);
         }
         k_finish_sums<<<(unsigned)k, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
         HIP_TRY(hipGetLastError());

@@ -81,6 +81,74 @@ static FF_HD fe sh_ab_sum(const Sh<NC>& x) {
     return Fr::add(x.c[0], x.c[NC - 1]);
 }
 
+// ---- lazy dot products: sum_i x_i * y_i with ONE Montgomery reduction at the end.
+// A Montgomery product is 128 multiply-adds (64 for x * y, 64 for the reduction) + their carries; a dot product only needs
+// the reduction once.  FrWide keeps the 15 columns of the 8 x 8 limb products as 96-bit accumulators (v_mad_u64_u32's
+// carry-out folded into `hi`, ff_macc.inc): 64 mads + 64 addc per term, good for 2^29 terms; fr_wide_reduce turns the
+// 544-bit total T = T0 + T1 R + T2 R^2 into T / R mod r = from_mont(T0) + (T1 mod r) + to_mont(T2): the same field element
+// as the sum of the individually reduced products.  This is what makes evaluate_at_chi / linear_combination HBM-bound
+// instead of multiplier-bound.
+struct FrWide {
+    uint64_t lo[15];
+    uint32_t hi[15];
+};
+#if defined(__HIP_DEVICE_COMPILE__)
+static __device__ __forceinline__ void fr_wide_zero(FrWide& w) {
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        w.lo[k] = 0;
+        w.hi[k] = 0;
+    }
+}
+static __device__ __forceinline__ void fr_wide_mac(FrWide& w, const fe& a, const fe& b) {
+    const uint32_t* A = a.l;
+    const uint32_t* B = b.l;
+    MACC1_VV(w.lo[0], w.hi[0], A[0], B[0]);
+    MACC2_VV(w.lo[1], w.hi[1], A[0], A[1], B[1], B[0]);
+    MACC3_VV(w.lo[2], w.hi[2], A[0], A[1], A[2], B[2], B[1], B[0]);
+    MACC4_VV(w.lo[3], w.hi[3], A[0], A[1], A[2], A[3], B[3], B[2], B[1], B[0]);
+    MACC5_VV(w.lo[4], w.hi[4], A[0], A[1], A[2], A[3], A[4], B[4], B[3], B[2], B[1], B[0]);
+    MACC6_VV(w.lo[5], w.hi[5], A[0], A[1], A[2], A[3], A[4], A[5], B[5], B[4], B[3], B[2], B[1], B[0]);
+    MACC7_VV(w.lo[6], w.hi[6], A[0], A[1], A[2], A[3], A[4], A[5], A[6], B[6], B[5], B[4], B[3], B[2], B[1], B[0]);
+    MACC8_VV(w.lo[7], w.hi[7], A[0], A[1], A[2], A[3], A[4], A[5], A[6], A[7], B[7], B[6], B[5], B[4], B[3], B[2], B[1], B[0]);
+    MACC7_VV(w.lo[8], w.hi[8], A[1], A[2], A[3], A[4], A[5], A[6], A[7], B[7], B[6], B[5], B[4], B[3], B[2], B[1]);
+    MACC6_VV(w.lo[9], w.hi[9], A[2], A[3], A[4], A[5], A[6], A[7], B[7], B[6], B[5], B[4], B[3], B[2]);
+    MACC5_VV(w.lo[10], w.hi[10], A[3], A[4], A[5], A[6], A[7], B[7], B[6], B[5], B[4], B[3]);
+    MACC4_VV(w.lo[11], w.hi[11], A[4], A[5], A[6], A[7], B[7], B[6], B[5], B[4]);
+    MACC3_VV(w.lo[12], w.hi[12], A[5], A[6], A[7], B[7], B[6], B[5]);
+    MACC2_VV(w.lo[13], w.hi[13], A[6], A[7], B[7], B[6]);
+    MACC1_VV(w.lo[14], w.hi[14], A[7], B[7]);
+}
+static __device__ __forceinline__ fe fr_wide_reduce(const FrWide& w) {
+    uint32_t t[18];
+    uint64_t carry = 0;  // < 2^64: a column is < 2^96, so (column + carry) >> 32 < 2^64
+#pragma unroll
+    for (int k = 0; k < 15; k++) {
+        uint64_t s = w.lo[k] + carry;
+        uint32_t h = w.hi[k] + (s < carry ? 1u : 0u);
+        t[k] = (uint32_t)s;
+        carry = (s >> 32) | ((uint64_t)h << 32);
+    }
+    t[15] = (uint32_t)carry;
+    t[16] = (uint32_t)(carry >> 32);
+    t[17] = 0;
+    fe t0, t1, t2 = Fr::zero();
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        t0.l[i] = t[i];
+        t1.l[i] = t[8 + i];
+    }
+    t2.l[0] = t[16];
+    t2.l[1] = t[17];
+    fe r = Fr::add(Fr::from_mont(t0), Fr::to_mont(Fr::from_mont(t1)));
+    return Fr::add(r, Fr::to_mont(t2));
+}
+#else  // host pass of the kernels' bodies: declarations only (the multiply-add chains are device assembly)
+__device__ void fr_wide_zero(FrWide& w);
+__device__ void fr_wide_mac(FrWide& w, const fe& a, const fe& b);
+__device__ fe fr_wide_reduce(const FrWide& w);
+#endif
+
 // ---- reductions of field elements: wave shuffle tree, then LDS across the 4 waves of a block
 static __device__ __forceinline__ fe fr_wave_sum(fe v) {
 #pragma unroll
