@@ -504,9 +504,68 @@ struct Field {
 
     static FF_HD fe to_mont(const fe& a) { return mul(a, r2()); }
     static FF_HD fe from_mont(const fe& a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // REDC of the 256-bit value itself: the product-scanning Montgomery product above with the a * b columns replaced
+        // by a's limbs -- 36 + 28 multiply-adds instead of 128, and no second operand to hold in registers
+        uint64_t lo = 0;
+        uint32_t hi = 0;
+        uint32_t m[8], r[8];
+        const uint32_t* A = a.l;
+#define P_(j) Pm::MOD[j]
+#define SHIFT_() lo = (lo >> 32) | ((uint64_t)hi << 32); hi = 0
+#define ADDA_(k) { uint64_t t_ = lo + A[k]; hi += t_ < lo ? 1u : 0u; lo = t_; }
+#define MSTEP_(k) m[k] = (uint32_t)lo * Pm::INV; MACC1_VS(lo, hi, m[k], P_(0)); SHIFT_()
+        ADDA_(0);
+        MSTEP_(0);
+        ADDA_(1);
+        MACC1_VS(lo, hi, m[0], P_(1));
+        MSTEP_(1);
+        ADDA_(2);
+        MACC2_VS(lo, hi, m[0], m[1], P_(2), P_(1));
+        MSTEP_(2);
+        ADDA_(3);
+        MACC3_VS(lo, hi, m[0], m[1], m[2], P_(3), P_(2), P_(1));
+        MSTEP_(3);
+        ADDA_(4);
+        MACC4_VS(lo, hi, m[0], m[1], m[2], m[3], P_(4), P_(3), P_(2), P_(1));
+        MSTEP_(4);
+        ADDA_(5);
+        MACC5_VS(lo, hi, m[0], m[1], m[2], m[3], m[4], P_(5), P_(4), P_(3), P_(2), P_(1));
+        MSTEP_(5);
+        ADDA_(6);
+        MACC6_VS(lo, hi, m[0], m[1], m[2], m[3], m[4], m[5], P_(6), P_(5), P_(4), P_(3), P_(2), P_(1));
+        MSTEP_(6);
+        ADDA_(7);
+        MACC7_VS(lo, hi, m[0], m[1], m[2], m[3], m[4], m[5], m[6], P_(7), P_(6), P_(5), P_(4), P_(3), P_(2), P_(1));
+        MSTEP_(7);
+        MACC7_VS(lo, hi, m[1], m[2], m[3], m[4], m[5], m[6], m[7], P_(7), P_(6), P_(5), P_(4), P_(3), P_(2), P_(1));
+        r[0] = (uint32_t)lo; SHIFT_();
+        MACC6_VS(lo, hi, m[2], m[3], m[4], m[5], m[6], m[7], P_(7), P_(6), P_(5), P_(4), P_(3), P_(2));
+        r[1] = (uint32_t)lo; SHIFT_();
+        MACC5_VS(lo, hi, m[3], m[4], m[5], m[6], m[7], P_(7), P_(6), P_(5), P_(4), P_(3));
+        r[2] = (uint32_t)lo; SHIFT_();
+        MACC4_VS(lo, hi, m[4], m[5], m[6], m[7], P_(7), P_(6), P_(5), P_(4));
+        r[3] = (uint32_t)lo; SHIFT_();
+        MACC3_VS(lo, hi, m[5], m[6], m[7], P_(7), P_(6), P_(5));
+        r[4] = (uint32_t)lo; SHIFT_();
+        MACC2_VS(lo, hi, m[6], m[7], P_(7), P_(6));
+        r[5] = (uint32_t)lo; SHIFT_();
+        MACC1_VS(lo, hi, m[7], P_(7));
+        r[6] = (uint32_t)lo;
+        r[7] = (uint32_t)(lo >> 32);
+#undef P_
+#undef SHIFT_
+#undef ADDA_
+#undef MSTEP_
+        fe o;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o.l[i] = r[i];
+        return reduce_once(o);
+#else
         fe o = zero();
         o.l[0] = 1;
         return mul(a, o);
+#endif
     }
     static FF_HD fe from_u64(uint64_t v) {
         fe o = zero();
