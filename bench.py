@@ -266,8 +266,8 @@ def run_rank(args):
                 "kernel_share_of_step": round(prof["total_ms"] / (dt * 1e3), 4),
                 "co_run": "the sort of the NEXT launch set (k_msm_hist_lds / k_msm_scatter_lds, 256-thread workgroups on a high-priority "
                           "stream) runs beside this kernel: both launch durations include the time they share the chip, their shares of "
-                          "the step add up to more than the commit phase; COZK_MSM_SERIAL=1 runs them back to back (the rocprofv3 "
-                          "summaries under profiles/ are taken that way)"}
+                          "the step add up to more than the commit phase; COZK_MSM_SERIAL=1 runs them back to back (profiles/ holds the "
+                          "rocprofv3 summary of this command in both modes)"}
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) of this same
     # command: bench.py cannot run rocprofv3 on itself, so the figure is a committed measurement, tagged with its source
     try:
