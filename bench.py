@@ -95,16 +95,31 @@ def launch_ranks(n, argv):
                    MASTER_PORT=port, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out0 = procs[0].communicate()[0].decode(errors="replace")
-    codes = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # drain rank 0's stdout on a thread and poll EVERY child: the first rank that fails ends the run at once (the others
+    # would otherwise sit in the rendezvous or a collective until its timeout, which can be minutes)
+    import threading
+    import time as _time
+    buf = []
+    reader = threading.Thread(target=lambda: buf.append(procs[0].stdout.read()), daemon=True)
+    reader.start()
+    codes = [None] * n
+    while any(c is None for c in codes):
+        for i, p in enumerate(procs):
+            if codes[i] is None:
+                codes[i] = p.poll()
+        if any(c not in (None, 0) for c in codes):
+            for p in procs:  # fresh children of this process, no exec involved: safe to end on a GPU box
+                if p.poll() is None:
+                    p.kill()
+            codes = [p.wait() for p in procs]
+            break
+        _time.sleep(0.05)
+    reader.join(timeout=10)
+    out0 = (buf[0] if buf else b"").decode(errors="replace")
     if any(codes):
-        # a failed rank leaves the others blocked in a collective until its timeout: end them now
-        for p in procs:
-            if p.poll() is None:
-                p.kill()
         sys.stderr.write("bench.py: rank exit codes %s\n" % codes)
         sys.stdout.write(out0)
-        return next(c for c in codes if c) or 1
+        return next((c for c in codes if c and c > 0), 1)
     lines = [ln for ln in out0.splitlines() if ln.startswith("{")]
     if len(lines) != 1:
         sys.stderr.write("bench.py: expected one JSON line from rank 0, got %d\n" % len(lines))
@@ -128,6 +143,8 @@ def main():
 def run_plumbing(args):
     """--plumbing-only: everything of a multi-rank run except the proving (CPU-only rehearsal of launch + rendezvous)"""
     import importlib
+    if os.environ.get("COZK_BENCH_TEST_FAIL_RANK") == os.environ.get("RANK", "0"):
+        sys.exit(3)  # test hook (tests/test_dist_cpu.py): this rank dies before the rendezvous
     dist = importlib.import_module("co-zkvms_amd.dist")
     grp = dist.Group(backend="gloo", device=None)
     grp.barrier()

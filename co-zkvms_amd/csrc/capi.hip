@@ -306,6 +306,10 @@ int cozk_rep3_scatter(cozk_ctx* dealer, const cozk_vec* v, const uint8_t key0[CO
             const size_t n = v->n;
             if (n == 0) return;
             const bool same = dealer->device == party_ctx->device;
+            // out_a / out_b come from the PARTY's pool, whose blocks are ordered by the party's stream only (common.hpp):
+            // a block the party has just freed may still be read by a kernel in flight there, so the dealer's stream must
+            // not write it before the party's stream has drained
+            HIP_TRY(hipStreamSynchronize(party_ctx->stream));
             fe *da = (fe*)(*out_a)->d, *db = (fe*)(*out_b)->d;
             fe *sa = da, *sb = db;
             if (!same) {

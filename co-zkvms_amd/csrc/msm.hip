@@ -822,6 +822,7 @@ static void msm_sort(cozk_ctx* ctx, hipStream_t st, MsmSortWs& sw, const MsmSetP
         static const int ltpb = getenv("COZK_MSM_LTPB") ? atoi(getenv("COZK_MSM_LTPB")) : 256;
         static const uint32_t wgs_max = getenv("COZK_MSM_WGS") ? (uint32_t)atoi(getenv("COZK_MSM_WGS")) : 64u;
         COZK_REQUIRE(ltpb >= 64 && ltpb <= LTPB && ltpb % 64 == 0, "COZK_MSM_LTPB out of range");
+        COZK_REQUIRE(wgs_max >= 1 && wgs_max <= 1024, "COZK_MSM_WGS out of range (1..1024)");
         uint32_t wgs = (uint32_t)((max_n + 4095) / 4096);  // >= 4096 scalars per workgroup (measured: 64 beats 16 workgroups 2x)
         if (wgs < 1) wgs = 1;
         if (wgs > wgs_max) wgs = wgs_max;

@@ -108,7 +108,9 @@ int cozk_rep3_share_vec(cozk_ctx* ctx, const cozk_vec* v, const uint8_t key0[COZ
 /* The witness scatter device to device (jolt/vm/jolt/coordinator.rs:72-91; receive_witness_share in jolt/vm/.../witness.rs):
  * as cozk_rep3_share_vec, but the secret lives on the DEALER's context and the outputs are vectors of `party_ctx` (another
  * GPU, or the same one): generated on the dealer's device, moved by a peer copy over xGMI when the devices differ.
- * Returns after the copy has completed. */
+ * Returns after the copy has completed.  The outputs are blocks of party_ctx's allocator: the call drains party_ctx's
+ * stream before the dealer's stream writes them, and -- like every call that takes a context -- must come from the
+ * thread that owns party_ctx (a context and its allocator are single-owner). */
 int cozk_rep3_scatter(cozk_ctx* dealer, const cozk_vec* v, const uint8_t key0[COZK_PRF_KEY_BYTES],
                       const uint8_t key1[COZK_PRF_KEY_BYTES], uint64_t counter, cozk_ctx* party_ctx, int party,
                       cozk_vec** out_a, cozk_vec** out_b);

@@ -67,6 +67,19 @@ def test_bench_self_launch_reports_a_failed_rank():
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
 
 
+def test_bench_self_launch_one_late_rank_fails_fast():
+    """rank 1 dies before the rendezvous while rank 0 waits in it -- the parent polls every child, ends rank 0 and
+    returns rank 1's exit code at once instead of waiting for the rendezvous to time out"""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["COZK_BENCH_TEST_FAIL_RANK"] = "1"
+    t0 = time.time()
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--plumbing-only"], env=env, capture_output=True, timeout=300)
+    assert p.returncode == 3, (p.returncode, p.stderr.decode())
+    assert time.time() - t0 < 120
+    assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+
+
 def test_bench_rejects_world_size_mismatch():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing-only"], env=env, capture_output=True, timeout=120)

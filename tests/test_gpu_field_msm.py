@@ -197,3 +197,32 @@ def test_rep3_scatter_device_to_device(cozk, ctx):
             a.free()
             b.free()
         party_ctx.close()
+
+
+def test_rep3_scatter_orders_against_the_party_stream(cozk, ctx):
+    """the scatter's outputs are blocks of the PARTY's allocator but are written from the dealer's stream.  A block
+    the party freed a moment ago may still be read by a kernel in flight on the party's stream: the scatter must not
+    overwrite it early.  Queue reads of X on the party's stream, free X, scatter a vector of the same size straight after
+    (the allocator hands X's block back), and check what the queued reads produced."""
+    n = 1 << 20
+    party_ctx = cozk.Context(0)
+    X = cozk.Vec.random(party_ctx, n, seed=4242)
+    acc = X.binop(cozk.OP_ADD, X)
+    for _ in range(8):  # a queue of kernels that all read X
+        nxt = acc.binop(cozk.OP_ADD, X)
+        acc.free()
+        acc = nxt
+    X.free()
+    V = cozk.Vec.random(ctx, n, seed=77)
+    k0, k1 = O.harness_prf_key(63, 0), O.harness_prf_key(64, 0)
+    a, b = V.rep3_scatter(k0, k1, 1, party_ctx, counter=0)
+    X2 = cozk.Vec.random(party_ctx, n, seed=4242)
+    want = X2.to_ints()
+    got = acc.to_ints()
+    assert got[:64] == [10 * x % O.R for x in want[:64]]
+    assert got[-64:] == [10 * x % O.R for x in want[-64:]]
+    ea, eb = V.rep3_share(k0, k1, 1, counter=0)
+    assert a.to_ints()[:32] == ea.to_ints()[:32] and b.to_ints()[-32:] == eb.to_ints()[-32:]
+    for v in (a, b, X2, acc, ea, eb, V):
+        v.free()
+    party_ctx.close()
