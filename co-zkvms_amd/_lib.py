@@ -101,6 +101,8 @@ SIGNATURES = {
     "cozk_poly_get_coeff": (_i, [_vp, _vp, _sz, _vp, _vp]),
     "cozk_eq_evals": (_i, [_vp, _vp, _i, _pp]),
     "cozk_poly_batch_evaluate_at_chi": (_i, [_vp, _vp, _sz, _vp, _vp]),
+    "cozk_eq_plus_one_evals": (_i, [_vp, _vp, _i, _pp]),
+    "cozk_poly_batch_dot_public": (_i, [_vp, _vp, _sz, _vp, _sz, _vp]),
     "cozk_poly_dot_product_with_public": (_i, [_vp, _vp, _vp, _vp, _vp]),
     "cozk_poly_linear_combination": (_i, [_vp, _vp, _vp, _sz, _i, _i, _pp]),
     "cozk_open_quadratic_evals": (_i, [_vp, _vp, _vp, _sz, _vp]),

@@ -20,6 +20,12 @@
 //   cross    0: flagc (next_pc - pc') = 0              1: flagc ((s0 + 5) - (q' + 5)) = 0            (' = next step)
 // 8 rows per step.  oracle/pyspartan_outer.py restates the reference's SPARSE algorithm on the same instance.
 #pragma once
+// cfg.system = 1 replaces the toy system by the reference's own constraint SET (co-jolt/src/r1cs/constraints.rs:39-257 over the 78
+// inputs of r1cs/inputs.rs: 70 uniform + 2 cross-step constraints, 128 rows per step) on a synthetic trace that satisfies it
+// (csrc/host/jolt_r1cs.hpp); cfg.full = 1 runs the WHOLE Spartan worker (outer + inner + shift sumchecks and the two opening
+// appends, r1cs/spartan/worker.rs:63-273; csrc/host/spartan_jolt.hpp) instead of the outer sumcheck alone.
+#include "jolt_r1cs.hpp"
+#include "spartan_jolt.hpp"
 
 struct OuterParty {
     cozk_ctx* ctx = nullptr;
@@ -27,45 +33,25 @@ struct OuterParty {
     int party = 0;
     std::vector<PolyH> cols;
     double t_build = 0, t_prove = 0, t_total = 0;
+    SpartanTimes times;
     uint64_t star_up = 0, star_down = 0, star_msgs = 0;
     std::string error;
 };
 
-struct OuterSystem {
-    std::vector<int> term_var;
-    std::vector<int64_t> term_coeff;
-    std::vector<cozk_lc> uniform, cross;
-    cozk_r1cs desc{};
-    cozk_lc add(std::initializer_list<std::pair<int, int64_t>> terms, int offset = 0) {
-        cozk_lc lc{(int)term_var.size(), (int)terms.size(), offset};
-        for (auto& t : terms) {
-            term_var.push_back(t.first);
-            term_coeff.push_back(t.second);
-        }
-        return lc;
-    }
-    void finish(size_t padded) {
-        desc.term_var = term_var.data();
-        desc.term_coeff = term_coeff.data();
-        desc.n_terms = term_var.size();
-        desc.uniform = uniform.data();
-        desc.n_uniform = uniform.size() / 3;
-        desc.cross = cross.data();
-        desc.n_cross = cross.size() / 3;
-        desc.padded_num_constraints = padded;
-    }
-};
+typedef jolt::System OuterSystem;
 
 struct cozk_outer_harness {
     cozk_outer_config cfg;
     int nparties = 1;
     size_t N = 0;
-    static constexpr int NCOLS = 14;
-    static constexpr size_t PADDED = 8;
+    int ncols = 14;
     std::vector<OuterParty> parties;
     OuterSystem sys;
-    std::vector<std::vector<fe>> clear;  // the dealer's view of the 14 columns
-    bool is_public[NCOLS] = {false, false, false, false, true, true, false, false, true, false, false, false, true, false};
+    std::vector<std::vector<fe>> clear;  // the dealer's view of the columns
+    std::vector<int> is_public;
+    // the verifier's own view (cfg.full): the clear columns as plain polynomials on its own context, made at the first verify
+    cozk_ctx* vctx = nullptr;
+    std::vector<PolyH> v_cols;
     std::string error;
     Bytes last_proof;
 };
@@ -73,24 +59,30 @@ struct cozk_outer_harness {
 namespace {
 
 void outer_build_system(OuterSystem& s) {
+    using jolt::LC;
     const int C = -1;  // the constant "variable"
+    auto L = [](std::initializer_list<std::pair<int, int64_t>> t) { return LC(t); };
     // uniform constraints: a, b, c
-    s.uniform = {s.add({{0, 1}, {1, 2}, {C, 3}}), s.add({{2, 1}, {3, -1}}), s.add({{6, 1}}),
-                 s.add({{4, 1}, {C, 1}}), s.add({{1, 1}, {2, 1}}), s.add({{7, 1}}),
-                 s.add({{4, 1}}), s.add({{5, 1}, {C, -1}}), s.add({{8, 1}}),
-                 s.add({{5, 1}}), s.add({{0, 1}}), s.add({{9, 1}}),
-                 s.add({}), s.add({{1, 1}}), s.add({})};
+    s.add_uniform(L({{0, 1}, {1, 2}, {C, 3}}), L({{2, 1}, {3, -1}}), L({{6, 1}}));
+    s.add_uniform(L({{4, 1}, {C, 1}}), L({{1, 1}, {2, 1}}), L({{7, 1}}));
+    s.add_uniform(L({{4, 1}}), L({{5, 1}, {C, -1}}), L({{8, 1}}));
+    s.add_uniform(L({{5, 1}}), L({{0, 1}}), L({{9, 1}}));
+    s.add_uniform(L({}), L({{1, 1}}), L({}));
     // cross-step constraints: a, b, cond
-    s.cross = {s.add({{11, 1}}), s.add({{10, 1}}, 1), s.add({{12, 1}}),
-               s.add({{0, 1}, {C, 5}}), s.add({{13, 1}, {C, 5}}, 1), s.add({{12, 1}})};
-    s.finish(cozk_outer_harness::PADDED);
+    s.add_cross(L({{11, 1}}), 0, L({{10, 1}}), 1, L({{12, 1}}), 0);
+    s.add_cross(L({{0, 1}, {C, 5}}), 0, L({{13, 1}, {C, 5}}), 1, L({{12, 1}}), 0);
+    s.finish(14);
 }
 
 void outer_build_clear(cozk_outer_harness* h) {
     const uint64_t seed = h->cfg.seed;
     const size_t N = h->N;
     auto& c = h->clear;
-    c.assign(cozk_outer_harness::NCOLS, std::vector<fe>(N));
+    if (h->cfg.system == 1) {
+        jolt::build_clear(seed, N, c);
+        return;
+    }
+    c.assign(14, std::vector<fe>(N));
     const fe one = Fr::one();
     for (size_t x = 0; x < N; x++) {
         for (int v = 0; v < 4; v++) c[v][x] = synthetic_fr_host(seed + 100ull * (uint64_t)(v + 1), x);
@@ -111,7 +103,7 @@ void outer_build_clear(cozk_outer_harness* h) {
 
 void outer_setup_party(cozk_outer_harness* h, OuterParty& ps) {
     cozk_ctx* ctx = ps.ctx;
-    for (int v = 0; v < cozk_outer_harness::NCOLS; v++) {
+    for (int v = 0; v < h->ncols; v++) {
         cozk_vec* pv = nullptr;
         rc_check(cozk_vec_upload(ctx, h->clear[v].data(), h->N, COZK_SCALAR_FR, &pv), ctx, "vec_upload(column)");
         VecH plain(pv);
@@ -132,9 +124,15 @@ void outer_setup_party(cozk_outer_harness* h, OuterParty& ps) {
 }
 
 struct OuterProofBundle {
+    bool full = false;
     OuterSumcheckProof outer;
+    JoltSpartanProof spartan;
     Bytes serialize() const {
         Writer w;
+        if (full) {
+            spartan.write(w);
+            return w.b;
+        }
         w.u64(outer.compressed_polys.size());
         for (auto& p : outer.compressed_polys) w.vec_fr(p);
         w.vec_fr(outer.claims);
@@ -151,21 +149,33 @@ void outer_worker_main(cozk_outer_harness* h, OuterParty& ps, StarNetWorker* sta
     env.ring = nullptr;  // Az (x) Bz is summed, never reshared: no ring on this path
     HIP_TRY(hipSetDevice(ps.ctx->device));
     double t0 = now_ms();
-    Bytes req = env.star->receive_request();
-    Reader rd(req);
-    std::vector<fe> tau = rd.vec_fr();
-    std::vector<uint64_t> w = to_abi(tau);
-    std::vector<const cozk_poly*> cols;
-    for (auto& c : ps.cols) cols.push_back(c.h);
-    cozk_outer* st = nullptr;
-    rc_check(cozk_outer_create(env.ctx, env.mode, ps.party, &h->sys.desc, cols.data(), cols.size(), w.data(), tau.size(), &st), env.ctx, "outer_create");
-    OuterH sth(st);
-    double t1 = now_ms();
-    ps.t_build = t1 - t0;
-    (void)prove_spartan_cubic_sumcheck_worker(env, st, (int)tau.size());
-    double t2 = now_ms();
-    ps.t_prove = t2 - t1;
-    ps.t_total = t2 - t0;
+    if (h->cfg.full) {
+        std::vector<cozk_poly*> cols;
+        for (auto& c : ps.cols) cols.push_back(c.h);
+        Rep3ProverOpeningAccumulator acc;  // the two openings stay here (a whole Jolt proof reduces them with all the others)
+        ps.times = SpartanTimes();
+        prove_spartan_worker(env, h->sys, cols, h->N, acc, &ps.times);
+        double t2 = now_ms();
+        ps.t_build = ps.times.t_build;
+        ps.t_prove = t2 - t0 - ps.times.t_build;
+        ps.t_total = t2 - t0;
+    } else {
+        Bytes req = env.star->receive_request();
+        Reader rd(req);
+        std::vector<fe> tau = rd.vec_fr();
+        std::vector<uint64_t> w = to_abi(tau);
+        std::vector<const cozk_poly*> cols;
+        for (auto& c : ps.cols) cols.push_back(c.h);
+        cozk_outer* st = nullptr;
+        rc_check(cozk_outer_create(env.ctx, env.mode, ps.party, &h->sys.desc, cols.data(), cols.size(), w.data(), tau.size(), &st), env.ctx, "outer_create");
+        OuterH sth(st);
+        double t1 = now_ms();
+        ps.t_build = t1 - t0;
+        (void)prove_spartan_cubic_sumcheck_worker(env, st, (int)tau.size());
+        double t2 = now_ms();
+        ps.t_prove = t2 - t1;
+        ps.t_total = t2 - t0;
+    }
     ps.star_up = star->bytes_up;
     ps.star_down = star->bytes_down;
     ps.star_msgs = star->n_msgs;
@@ -173,7 +183,7 @@ void outer_worker_main(cozk_outer_harness* h, OuterParty& ps, StarNetWorker* sta
 
 // the dealer's Az, Bz, Cz in the clear, row by row, and their multilinear extensions at the big-endian point pt
 void outer_clear_claims(cozk_outer_harness* h, const std::vector<fe>& pt, fe out[3]) {
-    const size_t N = h->N, P = cozk_outer_harness::PADDED;
+    const size_t N = h->N, P = h->sys.padded;
     const OuterSystem& s = h->sys;
     std::vector<fe> eq = eq_evals_host(pt);
     auto lc_eval = [&](const cozk_lc& lc, size_t step) {
@@ -216,9 +226,64 @@ void outer_clear_claims(cozk_outer_harness* h, const std::vector<fe>& pt, fe out
     }
 }
 
+// the verifier's columns: the dealer's clear values as plain polynomials on a context of their own
+void outer_setup_verifier(cozk_outer_harness* h) {
+    if (h->vctx) return;
+    int rc = cozk_ctx_create(h->cfg.devices[0], &h->vctx);
+    if (rc != COZK_OK) throw CozkError(rc, "outer harness: cannot create the verifier's context");
+    HIP_TRY(hipSetDevice(h->vctx->device));
+    for (int v = 0; v < h->ncols; v++) {
+        cozk_vec* pv = nullptr;
+        rc_check(cozk_vec_upload(h->vctx, h->clear[v].data(), h->N, COZK_SCALAR_FR, &pv), h->vctx, "vec_upload(column)");
+        VecH plain(pv);
+        cozk_poly* p = nullptr;
+        rc_check(cozk_poly_create(h->vctx, COZK_MODE_PLAIN, plain.h, nullptr, &p), h->vctx, "poly_create");
+        h->v_cols.push_back(PolyH(p));
+    }
+}
+
+// claims[i] == column_i(point) for every column (stand-in for the PCS opening of the flattened witness)
+bool outer_check_openings(cozk_outer_harness* h, const std::vector<fe>& point, const std::vector<fe>& claims) {
+    HIP_TRY(hipSetDevice(h->vctx->device));
+    std::vector<uint64_t> w = to_abi(point);
+    cozk_vec* chi = nullptr;
+    rc_check(cozk_eq_evals(h->vctx, w.data(), (int)point.size(), &chi), h->vctx, "eq_evals");
+    VecH chih(chi);
+    std::vector<const cozk_poly*> ps;
+    for (auto& c : h->v_cols) ps.push_back(c.h);
+    std::vector<uint64_t> out(4 * ps.size());
+    rc_check(cozk_poly_batch_evaluate_at_chi(h->vctx, ps.data(), ps.size(), chih.h, out.data()), h->vctx, "batch_evaluate");
+    if (claims.size() != ps.size()) return false;
+    for (size_t i = 0; i < ps.size(); i++)
+        if (!Fr::eq(fe_from_u64x4(out.data() + 4 * i), claims[i])) return false;
+    return true;
+}
+
 int outer_coordinator_main(cozk_outer_harness* h, StarNetCoordinator& net, OuterProofBundle& proof, bool verify, std::string& why) {
+    int constr_bits = 0;
+    while (((size_t)1 << constr_bits) < h->sys.padded) constr_bits++;
+    if (h->cfg.full) {
+        proof.full = true;
+        Transcript tr("cozk-spartan");
+        proof.spartan = coordinate_spartan(net, tr, h->sys, h->N);
+        if (!verify) return -1;
+        Transcript vt("cozk-spartan");
+        std::vector<fe> rx_step, shift_r;
+        fe rho[2];
+        if (!verify_spartan(proof.spartan, h->sys, h->N, vt, rx_step, shift_r, rho, why)) return 0;
+        outer_setup_verifier(h);
+        if (!outer_check_openings(h, rx_step, proof.spartan.witness_evals)) {
+            why = "spartan: claimed_witness_evals != the columns at rx_step";
+            return 0;
+        }
+        if (!outer_check_openings(h, shift_r, proof.spartan.shift_witness_evals)) {
+            why = "spartan: shift_sumcheck_witness_evals != the columns at the shift point";
+            return 0;
+        }
+        return 1;
+    }
     Transcript tr("cozk-spartan-outer");
-    int num_rounds = h->cfg.log_steps + 3;  // log2(steps * 8 rows)
+    int num_rounds = h->cfg.log_steps + constr_bits;  // log2(steps * padded rows per step)
     std::vector<fe> tau = tr.challenge_vector((size_t)num_rounds);
     {
         Writer w;
@@ -234,6 +299,7 @@ int outer_coordinator_main(cozk_outer_harness* h, StarNetCoordinator& net, Outer
         why = "outer sumcheck: a round or the final claim does not hold";
         return 0;
     }
+    if ((h->N << constr_bits) > ((size_t)1 << 22)) return 1;  // the row-by-row host evaluation below is for test sizes
     std::vector<fe> pt(rv.rbegin(), rv.rend());
     fe direct[3];
     outer_clear_claims(h, pt, direct);
@@ -257,9 +323,18 @@ int cozk_outer_harness_create(const cozk_outer_config* cfg, cozk_outer_harness**
     try {
         COZK_REQUIRE(cfg->mode == COZK_MODE_PLAIN || cfg->mode == COZK_MODE_REP3, "outer harness: mode");
         COZK_REQUIRE(cfg->log_steps >= 0 && cfg->log_steps <= 22, "outer harness: log_steps in 0..22");
+        COZK_REQUIRE((cfg->system == 0 || cfg->system == 1) && (cfg->full == 0 || cfg->full == 1), "outer harness: system / full are 0 or 1");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->N = (size_t)1 << cfg->log_steps;
-        outer_build_system(h->sys);
+        if (cfg->system == 1) {
+            jolt::build_system(h->sys);
+            h->ncols = jolt::NUM_INPUTS;
+            for (int v = 0; v < h->ncols; v++) h->is_public.push_back(jolt::public_bytes(v) ? 1 : 0);
+        } else {
+            outer_build_system(h->sys);
+            h->ncols = 14;
+            h->is_public = {0, 0, 0, 0, 1, 1, 0, 0, 1, 0, 0, 0, 1, 0};
+        }
         outer_build_clear(h);
         h->parties.resize(h->nparties);
         for (int p = 0; p < h->nparties; p++) {
@@ -292,6 +367,11 @@ int cozk_outer_harness_destroy(cozk_outer_harness* h) {
         if (ps.ctx) (void)hipSetDevice(ps.ctx->device);
         ps.cols.clear();
         if (ps.own_ctx && ps.ctx) cozk_ctx_destroy(ps.ctx);
+    }
+    if (h->vctx) {
+        (void)hipSetDevice(h->vctx->device);
+        h->v_cols.clear();
+        cozk_ctx_destroy(h->vctx);
     }
     delete h;
     return COZK_OK;
@@ -349,6 +429,10 @@ int cozk_outer_harness_prove(cozk_outer_harness* h, int verify, cozk_outer_resul
         res->t_build_ms = std::max(res->t_build_ms, ps.t_build);
         res->t_prove_ms = std::max(res->t_prove_ms, ps.t_prove);
         res->t_worker_ms = std::max(res->t_worker_ms, ps.t_total);
+        res->t_outer_ms = std::max(res->t_outer_ms, ps.times.t_outer);
+        res->t_inner_ms = std::max(res->t_inner_ms, ps.times.t_inner);
+        res->t_shift_ms = std::max(res->t_shift_ms, ps.times.t_shift);
+        res->t_openings_ms = std::max(res->t_openings_ms, ps.times.t_openings);
         res->bytes_star_up += ps.star_up;
         res->bytes_star_down += ps.star_down;
         res->star_messages += ps.star_msgs;

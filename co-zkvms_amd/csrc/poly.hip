@@ -2321,4 +2321,5 @@ int cozk_layer_claimed_outputs(cozk_ctx* ctx, const cozk_layer* l, uint64_t* out
 #include "toggle_layer.inc"
 #include "primary_sumcheck.inc"
 #include "spartan_outer.inc"
+#include "spartan_inner.inc"
 #include "logup.inc"

@@ -9,12 +9,14 @@ from .engine import fr_to_mont_limbs, mont_limbs_to_int
 
 
 class OuterConfig(ctypes.Structure):
-    _fields_ = [("mode", ctypes.c_int), ("log_steps", ctypes.c_int), ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64)]
+    _fields_ = [("mode", ctypes.c_int), ("log_steps", ctypes.c_int), ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64),
+                ("system", ctypes.c_int), ("full", ctypes.c_int)]
 
 
 class OuterResult(ctypes.Structure):
     _fields_ = [("verified", ctypes.c_int), ("wall_ms", ctypes.c_double), ("t_build_ms", ctypes.c_double), ("t_prove_ms", ctypes.c_double),
-                ("t_worker_ms", ctypes.c_double), ("bytes_star_up", ctypes.c_uint64), ("bytes_star_down", ctypes.c_uint64),
+                ("t_worker_ms", ctypes.c_double), ("t_outer_ms", ctypes.c_double), ("t_inner_ms", ctypes.c_double), ("t_shift_ms", ctypes.c_double),
+                ("t_openings_ms", ctypes.c_double), ("bytes_star_up", ctypes.c_uint64), ("bytes_star_down", ctypes.c_uint64),
                 ("star_messages", ctypes.c_uint64), ("proof_len", ctypes.c_uint64), ("proof_digest", ctypes.c_uint8 * 32)]
 
 
@@ -30,7 +32,7 @@ class R1CS(ctypes.Structure):
 
 OUTER_SYMBOLS = ["cozk_outer_harness_create", "cozk_outer_harness_error", "cozk_outer_harness_destroy", "cozk_outer_harness_prove",
                  "cozk_outer_harness_proof_bytes", "cozk_outer_create", "cozk_outer_free", "cozk_outer_len", "cozk_outer_download", "cozk_outer_round",
-                 "cozk_outer_final_evals"]
+                 "cozk_outer_final_evals", "cozk_eq_plus_one_evals", "cozk_poly_batch_dot_public"]
 _vp, _i, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t
 
 
@@ -62,9 +64,13 @@ def _decl():
 
 
 class OuterHarness:
-    def __init__(self, mode="plain", log_steps=4, devices=(0, 0, 0), seed=1):
+    def __init__(self, mode="plain", log_steps=4, devices=(0, 0, 0), seed=1, system="toy", full=False):
+        """system = "jolt": the reference's constraint set (70 + 2 constraints, 78 inputs, 128 rows per step); full: the whole
+        Spartan worker (outer + inner + shift sumchecks + the two opening appends)"""
         self._l = _decl()
         cfg = OuterConfig()
+        cfg.system = 1 if system == "jolt" else 0
+        cfg.full = 1 if full else 0
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
         cfg.log_steps = log_steps
         cfg.devices = (ctypes.c_int * 3)(*devices)

@@ -169,6 +169,25 @@ def eq_evals(ctx, r):
     return Vec(ctx, h, L.SCALAR_FR)
 
 
+def eq_plus_one_evals(ctx, r):
+    """EqPlusOnePolynomial::evals(r, None).1 (cozk_eq_plus_one_evals; co-jolt/src/r1cs/spartan/worker.rs:116) as a device Vec"""
+    rr = fr_to_mont_limbs(r) if len(r) else np.zeros((0, 4), dtype=np.uint64)
+    h = ctypes.c_void_p()
+    ctx.check(ctx._l.cozk_eq_plus_one_evals(ctx.h, rr.ctypes.data if len(r) else None, len(r), ctypes.byref(h)))
+    return Vec(ctx, h, L.SCALAR_FR)
+
+
+def batch_dot_public(polys, pubs):
+    """bind_z / bind_shift_z (worker.rs:139-152): dot_product_with_public of every polynomial with 1 or 2 public Vecs in one
+    pass -> out[p][q] = (a, b) share (b = 0 for a plain / public polynomial)"""
+    ctx = polys[0].ctx
+    k, nq = len(polys), len(pubs)
+    out = np.zeros((k * nq * 2, 4), dtype=np.uint64)
+    ctx.check(ctx._l.cozk_poly_batch_dot_public(ctx.h, _ptr_array(polys), k, _ptr_array(pubs), nq, out.ctypes.data))
+    v = mont_limbs_to_int(out)
+    return [[(v[(p * nq + q) * 2], v[(p * nq + q) * 2 + 1]) for q in range(nq)] for p in range(k)]
+
+
 def open_quadratic_evals(polys, eqs):
     """inner sums of compute_quadratic (opening_proof.rs:374-414) -> [(eval_0, eval_2)] additive"""
     ctx = polys[0].ctx

@@ -439,6 +439,15 @@ int cozk_outer_download(cozk_ctx* ctx, const cozk_outer* st, uint64_t* az_a, uin
 int cozk_outer_round(cozk_ctx* ctx, cozk_outer* st, const uint64_t* r, const uint64_t claim[4], uint64_t out_coeffs[16]);
 /* final_sumcheck_evals (:648-664) after binding with the last challenge: additive Az(r), Bz(r), Cz(r) */
 int cozk_outer_final_evals(cozk_ctx* ctx, cozk_outer* st, const uint64_t r[4], uint64_t out[12]);
+/* ---- Spartan inner / shift sumchecks (co-jolt/src/r1cs/spartan/worker.rs:100-275).
+ * EqPlusOnePolynomial::evals(r, None).1 (jolt-core, used worker.rs:116): out[y] = eq_plus_one(r, y), big-endian, 2^nv entries;
+ * eq_plus_one(x, y) = 1 iff y = x + 1 and x < 2^nv - 1 (no wrap-around).  The eq half of the pair is cozk_eq_evals. */
+int cozk_eq_plus_one_evals(cozk_ctx* ctx, const uint64_t* r, int nv, cozk_vec** out);
+/* bind_z / bind_shift_z (worker.rs:139-152): dot_product_with_public (dense_mlpoly.rs:228-234) of k polynomials of one length
+ * with n_pub = 1 or 2 public vectors in ONE pass over the polynomials.  out[(p * n_pub + q) * 8 ..] = share (a[4], b[4]);
+ * b = 0 for a PLAIN polynomial (the dot product of a public polynomial is a public value) */
+int cozk_poly_batch_dot_public(cozk_ctx* ctx, const cozk_poly* const* polys, size_t k, const cozk_vec* const* pubs,
+                               size_t n_pub, uint64_t* out);
 
 /* ---- co-noir-spartan's public lookup round (co-noir-spartan/co-spartan/src/worker.rs:400-575,694-724,836-846;
  * co-noir-spartan/spartan/src/logup.rs:31-80; co-spartan/src/sumcheck.rs:434-500): plain Fr data, no shares. */
@@ -711,13 +720,18 @@ int cozk_lookups_proof_bytes(const cozk_lookups* h, uint8_t* out, size_t cap);
 typedef struct cozk_outer_harness cozk_outer_harness;
 typedef struct cozk_outer_config {
     int mode;
-    int log_steps; /* steps (cycles) = 2^log_steps; rows = 8 * steps */
+    int log_steps; /* steps (cycles) = 2^log_steps; rows = 8 (toy system) or 128 (Jolt constraint set) per step */
     int devices[3];
     uint64_t seed;
+    int system; /* 0: the 7-constraint toy system; 1: the reference's own constraint SET (co-jolt/src/r1cs/constraints.rs:39-257,
+                 * 70 uniform + 2 cross-step constraints over the 78 inputs of r1cs/inputs.rs) on a synthetic satisfying trace */
+    int full;   /* 1: the whole Rep3UniformSpartanProver::prove (r1cs/spartan/worker.rs:63-273: outer + inner + shift sumchecks,
+                 * two batch_evaluate + opening appends); 0: the outer sumcheck alone */
 } cozk_outer_config;
 typedef struct cozk_outer_result {
     int verified;
     double wall_ms, t_build_ms, t_prove_ms, t_worker_ms;
+    double t_outer_ms, t_inner_ms, t_shift_ms, t_openings_ms; /* cfg.full: the parts of t_prove_ms */
     uint64_t bytes_star_up, bytes_star_down, star_messages;
     uint64_t proof_len;
     uint8_t proof_digest[32];

@@ -433,3 +433,348 @@ def run(cfg):
         ok = [sum(a * b for a, b in zip(eq, vec)) % R for vec in (az, bz, cz)] == proof["claims"]
     blob = O.ser_u64(len(proof["round_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["round_polys"]) + O.ser_vec_fr(proof["claims"])
     return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": ok, "proof": proof, "rs": rs}
+
+
+# ================================================================================================ the WHOLE Spartan worker
+# Rep3UniformSpartanProver::prove (co-jolt/src/r1cs/spartan/worker.rs:63-273) + Rep3UniformSpartanCoordinator::prove_rep3
+# (r1cs/spartan/coordinator.rs:27-136): outer sumcheck (above), inner sumcheck over y = (shift bit | const bit | variable),
+# shift sumcheck over the steps, and the two batch_evaluate / append claim exchanges.
+#
+# Out of tree (jolt-core, restated from upstream knowledge; parity unpinned): EqPlusOnePolynomial::evals,
+# UniformSpartanKey::evaluate_matrix_mle_partial / evaluate_matrix_mle_full / evaluate_z_mle_with_segment_evals and the plain
+# verifier UniformSpartanProof::verify.  They are fixed here by the identities the in-tree worker relies on:
+#   Az(rx) + rlc Bz(rx) + rlc^2 Cz(rx) = sum_y ABC(rx_constr, y) z(y || rx_step)        (worker.rs:107-170)
+# with z's constant column = 1 in the non-shifted half only (bind_z[num_vars_uniform] = 1, :154).
+import pyjolt_r1cs as J
+
+
+def eq_plus_one_evals(r):
+    """EqPlusOnePolynomial::evals(r, None) -> (eq(r, .), eq_plus_one(r, .)): eq_plus_one(x, y) = 1 iff y = x + 1 as
+    big-endian integers, x < 2^l - 1 (no wrap-around), multilinear in x.  For y != 0 with k trailing zero bits:
+    x = y - 1 has its low k bits set, bit k clear and the high bits of y: value = prod_{low k} r_j * (1 - r_k) * eq(r_high, y_high)"""
+    l = len(r)
+    n = 1 << l
+    eq = O.eq_evals(r)
+    out = [0] * n
+    for y in range(1, n):
+        k = (y & -y).bit_length() - 1
+        v = 1
+        for j in range(k):  # low bits: r index l - 1 - j
+            v = v * r[l - 1 - j] % R
+        v = v * ((1 - r[l - 1 - k]) % R) % R
+        hi = y >> (k + 1)
+        m = l - k - 1
+        for j in range(m):
+            bit = (hi >> (m - 1 - j)) & 1
+            v = v * (r[j] if bit else (1 - r[j]) % R) % R
+        out[y] = v
+    return eq, out
+
+
+def matrix_mle_partial(uniform, cross, padded, nvars_padded, rx_constr, rlc):
+    """key.evaluate_matrix_mle_partial(rx_constr, rx_step, rlc) (used worker.rs:123-126): the 4 V entries of
+    ABC(rx_constr, .) = A + rlc B + rlc^2 C, V = nvars_padded: [variables | constant at V | shifted variables | (unused)]"""
+    V = nvars_padded
+    eq = O.eq_evals(rx_constr)
+    out = [0] * (4 * V)
+    r1, r2 = rlc % R, rlc * rlc % R
+
+    def add(lc, row, w, shifted=False, sign=1):
+        for var, c in lc:
+            col = V if var is None else (var + (2 * V if shifted else 0))
+            out[col] = (out[col] + sign * c * w % R * eq[row]) % R
+
+    for ci, (a, b, c) in enumerate(uniform):
+        add(a, ci, 1)
+        add(b, ci, r1)
+        add(c, ci, r2)
+    for ci, (a, b, cond) in enumerate(cross):
+        row = len(uniform) + ci
+        # Az = a - b, Bz = cond, Cz = 0; an offset LC reads the NEXT step: its variables land in the shifted half, its
+        # constant stays in the (non-shifted) constant column (sum_t eq(rx_step, t) = 1; at the last step an offset LC is
+        # its constant, eval_offset_lc_rep3_mixed spartan_interleaved_poly.rs:666-684, and eq_plus_one has no wrap-around)
+        for (off, lcx), w, sign in ((a, 1, 1), (b, 1, -1), (cond, r1, 1)):
+            for var, cf in lcx:
+                col = V if var is None else (var + (2 * V if off else 0))
+                out[col] = (out[col] + sign * cf * w % R * eq[row]) % R
+    return out
+
+
+# ---- MixedPolynomial (co-jolt/src/poly/mixed_polynomial.rs:12-193)
+def mixed_sumcheck_evals(evals, index, degree, party):
+    """sumcheck_evals, HighToLow (:48-59): values at 0, 2, .., degree"""
+    half = len(evals) // 2
+    out = [evals[index]]
+    if degree == 1:
+        return out
+    ev = evals[index + half]
+    m = sp_sub(ev, out[0], party)
+    for _ in range(1, degree):
+        ev = sp_add(ev, m, party)
+        out.append(ev)
+    return out
+
+
+def mixed_bind_top(evals, r, party):
+    """bound_poly_var_top (:78-89)"""
+    n = len(evals) // 2
+    return [sp_add(evals[i], sp_mul_public(sp_sub(evals[i + n], evals[i], party), r), party) for i in range(n)]
+
+
+def unipoly_from_evals_deg2(e0, e1, e2):
+    return O.unipoly_from_evals([e0, e1, e2])
+
+
+def prove_arbitrary_mixed(claims, num_rounds, polys_per_party, transcript):
+    """prove_arbitrary_worker (subprotocols/sumcheck.rs:168-246) with comb_func = (p0 * p1).into_additive, degree 2, over
+    MixedPolynomials, all parties in lock step with coordinate_prove_arbitrary (:134-165).  claims: per party additive.
+    Returns (compressed polys, r, per party final evals as additive)"""
+    np_ = len(polys_per_party)
+    prev = list(claims)
+    comps, rs = [], []
+    for _ in range(num_rounds):
+        msgs = []
+        for p in range(np_):
+            polys = polys_per_party[p]
+            half = len(polys[0]) // 2
+            acc = [0, 0]
+            for i in range(half):
+                ev = [mixed_sumcheck_evals(pl, i, 2, p) for pl in polys]
+                for j in range(2):
+                    acc[j] = (acc[j] + sp_into_additive(sp_mul(ev[0][j], ev[1][j]), p)) % R
+            pts = [acc[0], (prev[p] - acc[0]) % R, acc[1]]
+            msgs.append(O.unipoly_from_evals(pts))
+        poly = O.combine_additive(msgs)
+        comp = O.unipoly_compress(poly)
+        transcript.append_scalars(comp)
+        r_j = transcript.challenge_scalar()
+        rs.append(r_j)
+        comps.append(comp)
+        nxt = O.unipoly_eval(poly, r_j)
+        for p in range(np_):
+            prev[p] = O.additive_promote_from_trivial(nxt, p)
+            polys_per_party[p] = [mixed_bind_top(pl, r_j, p) for pl in polys_per_party[p]]
+    finals = [[sp_into_additive(pl[0], p) for pl in polys_per_party[p]] for p in range(np_)]
+    return comps, rs, finals
+
+
+def _dot_public(col, pub, party):
+    """Rep3MultilinearPolynomial::dot_product_with_public (multilinear_polynomial.rs; dense_mlpoly.rs:228-234): a public
+    polynomial gives a public value, a shared one a Rep3 share"""
+    kind, vals = col
+    if kind == "P":
+        return ("P", sum(v * w for v, w in zip(vals, pub)) % R)
+    acc = O.sh_zero(vals[0])
+    for v, w in zip(vals, pub):
+        acc = O.sh_add(acc, O.sh_mul_public(v, w))
+    return ("S", acc)
+
+
+def _batch_evaluate_additive(polys, chis, party):
+    """batch_evaluate + into_additive of every claim (worker.rs:243-272)"""
+    return [sp_into_additive(_dot_public(col, chis, party), party) for col in polys]
+
+
+def receive_claims(parts, transcript):
+    """Rep3ProverOpeningAccumulator::receive_claims (opening_proof.rs:108-128) -> (claims, rho, batched claim)"""
+    claims = O.combine_additive(parts)
+    rho = transcript.challenge_scalar()
+    pw, batched = 1, 0
+    for c in claims:
+        batched = (batched + pw * c) % R
+        pw = pw * rho % R
+    return claims, rho, batched
+
+
+def prove_full(uniform, cross, padded, polys_per_party, num_steps, transcript):
+    """the whole Rep3UniformSpartanProver::prove with its coordinator.  Returns the proof dict."""
+    np_ = len(polys_per_party)
+    nvars = len(polys_per_party[0])
+    steps_bits = num_steps.bit_length() - 1
+    constr_bits = padded.bit_length() - 1
+    V = 1
+    while V < nvars:
+        V <<= 1
+    tau = transcript.challenge_vector(steps_bits + constr_bits)
+    outer, rs = prove(uniform, cross, polys_per_party, padded, num_steps, tau, transcript)
+    outer_r = list(reversed(rs))
+    rx_step, rx_constr = outer_r[:steps_bits], outer_r[steps_bits:]
+    rlc = transcript.challenge_scalar()
+    az, bz, cz = outer["claims"]
+    claim_inner = (az + rlc * bz + rlc * rlc * cz) % R
+    eq_step, eqp1_step = eq_plus_one_evals(rx_step)
+    abc = matrix_mle_partial(uniform, cross, padded, V, rx_constr, rlc)
+    inner_polys = []
+    for p in range(np_):
+        bind_z = [sp_zero_public()] * (2 * V)
+        bind_shift = [sp_zero_public()] * (2 * V)
+        for i, col in enumerate(polys_per_party[p]):
+            bind_z[i] = _dot_public(col, eq_step, p)
+            bind_shift[i] = _dot_public(col, eqp1_step, p)
+        bind_z[V] = ("P", 1)
+        inner_polys.append([[("P", v) for v in abc], bind_z + bind_shift])
+    inner_rounds = (4 * V).bit_length() - 1
+    inner_comps, inner_r, _ = prove_arbitrary_mixed([O.additive_promote_from_trivial(claim_inner, p) for p in range(np_)], inner_rounds, inner_polys, transcript)
+    # shift sumcheck
+    ry_var = inner_r[1:]
+    eq_ry = O.eq_evals(ry_var)
+    shift_polys, shift_claims = [], []
+    for p in range(np_):
+        zry = []
+        for t in range(num_steps):
+            acc = sp_zero_public()
+            for i, (kind, vals) in enumerate(polys_per_party[p]):
+                acc = sp_add(acc, sp_mul_public((kind, vals[t]), eq_ry[i]), p)  # scale_coeff + sum_for (worker.rs:196-205)
+            zry.append(acc)
+        shift_polys.append([zry, [("P", v) for v in eqp1_step]])
+        shift_claims.append(sum(sp_into_additive(sp_mul(a, b), p) for a, b in zip(zry, shift_polys[p][1])) % R)
+    shift_claim = sum(shift_claims) % R  # combine_additive_share; NOT appended to the transcript (coordinator.rs:113-117)
+    shift_comps, shift_r, _ = prove_arbitrary_mixed(shift_claims, steps_bits, shift_polys, transcript)
+    chis1 = O.eq_evals(rx_step)
+    parts = [_batch_evaluate_additive(polys_per_party[p], chis1, p) for p in range(np_)]
+    witness_evals, rho1, batched1 = receive_claims(parts, transcript)
+    chis2 = O.eq_evals(shift_r)
+    parts = [_batch_evaluate_additive(polys_per_party[p], chis2, p) for p in range(np_)]
+    shift_evals, rho2, batched2 = receive_claims(parts, transcript)
+    return {"outer": outer, "outer_r": rs, "inner_polys": inner_comps, "inner_r": inner_r, "shift_claim": shift_claim, "shift_polys": shift_comps,
+            "shift_r": shift_r, "witness_evals": witness_evals, "shift_witness_evals": shift_evals, "rlc": rlc, "tau": tau,
+            "rho": [rho1, rho2], "batched": [batched1, batched2]}
+
+
+def _verify_rounds(comps, claim, degree, transcript):
+    rs = []
+    for comp in comps:
+        if len(comp) != degree:
+            return None, None
+        c1 = (claim - 2 * comp[0] - sum(comp[1:])) % R
+        poly = [comp[0], c1] + list(comp[1:])
+        transcript.append_scalars(comp)
+        r_j = transcript.challenge_scalar()
+        rs.append(r_j)
+        claim = O.unipoly_eval(poly, r_j)
+    return claim, rs
+
+
+def _eq_point(a, b):
+    e = 1
+    for x, y in zip(a, b):
+        e = e * ((x * y + (1 - x) * (1 - y)) % R) % R
+    return e
+
+
+def eq_plus_one_point(x, y):
+    """EqPlusOnePolynomial::evaluate (x, y big-endian points): sum over k of [low k bits: x = 1, y = 0][bit k: x = 0, y = 1][high: equal]"""
+    l = len(x)
+    acc = 0
+    for k in range(l):
+        v = 1
+        for j in range(k):
+            v = v * x[l - 1 - j] % R * ((1 - y[l - 1 - j]) % R) % R
+        v = v * ((1 - x[l - 1 - k]) % R) % R * y[l - 1 - k] % R
+        for j in range(l - k - 1):
+            v = v * ((x[j] * y[j] + (1 - x[j]) * (1 - y[j])) % R) % R
+        acc = (acc + v) % R
+    return acc
+
+
+def verify_full(proof, uniform, cross, padded, nvars, num_steps, transcript):
+    """the plain verifier's sumcheck checks (jolt-core UniformSpartanProof::verify, out of tree): returns True / False.
+    The opened witness evaluations themselves are checked by the opening proof (or, in the harness, against the dealer's
+    columns)."""
+    steps_bits = num_steps.bit_length() - 1
+    constr_bits = padded.bit_length() - 1
+    V = 1
+    while V < nvars:
+        V <<= 1
+    tau = transcript.challenge_vector(steps_bits + constr_bits)
+    rs = verify(proof["outer"], tau, transcript)
+    if rs is None:
+        return False
+    outer_r = list(reversed(rs))
+    rx_step, rx_constr = outer_r[:steps_bits], outer_r[steps_bits:]
+    rlc = transcript.challenge_scalar()
+    az, bz, cz = proof["outer"]["claims"]
+    claim = (az + rlc * bz + rlc * rlc * cz) % R
+    inner_rounds = (4 * V).bit_length() - 1
+    if len(proof["inner_polys"]) != inner_rounds:
+        return False
+    fin, inner_r = _verify_rounds(proof["inner_polys"], claim, 2, transcript)
+    if fin is None:
+        return False
+    ry_var = inner_r[1:]
+    eq_ry = O.eq_evals(ry_var)
+    z_eval = (sum(eq_ry[i] * proof["witness_evals"][i] for i in range(nvars)) + eq_ry[V]) % R
+    z_comb = ((1 - inner_r[0]) * z_eval + inner_r[0] * proof["shift_claim"]) % R
+    abc = matrix_mle_partial(uniform, cross, padded, V, rx_constr, rlc)
+    eq_y = O.eq_evals(inner_r)
+    abc_eval = sum(a * e for a, e in zip(abc, eq_y)) % R
+    if abc_eval * z_comb % R != fin:
+        return False
+    if len(proof["shift_polys"]) != steps_bits:
+        return False
+    fin, shift_r = _verify_rounds(proof["shift_polys"], proof["shift_claim"], 2, transcript)
+    if fin is None:
+        return False
+    z_shift = sum(eq_ry[i] * proof["shift_witness_evals"][i] for i in range(nvars)) % R
+    if z_shift * eq_plus_one_point(rx_step, shift_r) % R != fin:
+        return False
+    # receive_claims x 2
+    for _ in range(2):
+        transcript.challenge_scalar()
+    return rx_step, shift_r
+
+
+def jolt_party_columns(seed, cols, nparties):
+    """per party the ('P' | 'S', list) columns of the Jolt-shaped system: shared columns through rep3_share_vec with the
+    harness keys (seed + 100 (v + 1), 101 / 102)"""
+    nv = len(cols)
+    out = [[None] * nv for _ in range(nparties)]
+    for v in range(nv):
+        if J.IS_PUBLIC[v]:
+            for p in range(nparties):
+                out[p][v] = ("P", cols[v])
+        elif nparties == 1:
+            out[0][v] = ("S", cols[v])
+        else:
+            s = seed + 100 * (v + 1)
+            sh = O.rep3_share_vec(cols[v], O.harness_prf_key(s, 101), O.harness_prf_key(s, 102))
+            for p in range(3):
+                out[p][v] = ("S", sh[p])
+    return out
+
+
+def serialize_full(proof):
+    blob = O.ser_u64(len(proof["outer"]["round_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["outer"]["round_polys"]) + O.ser_vec_fr(proof["outer"]["claims"])
+    blob += O.ser_u64(len(proof["inner_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["inner_polys"])
+    blob += O.ser_fr(proof["shift_claim"])
+    blob += O.ser_u64(len(proof["shift_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["shift_polys"])
+    blob += O.ser_vec_fr(proof["witness_evals"]) + O.ser_vec_fr(proof["shift_witness_evals"])
+    return blob
+
+
+def run_full(cfg):
+    """the pipeline of csrc/host/outer_harness.hpp with cfg.system = jolt (full = 1): the whole Spartan worker on the
+    Jolt-shaped constraint system; returns proof bytes + verified"""
+    import hashlib
+    nparties = 1 if cfg["mode"] == "plain" else 3
+    n = 1 << cfg["log_steps"]
+    if cfg.get("system", "jolt") == "jolt":
+        uniform, cross, padded = J.build_system()
+        cols = J.synthetic_columns(cfg["seed"], n)
+        polys = jolt_party_columns(cfg["seed"], cols, nparties)
+    else:
+        uniform, cross, padded = synthetic_system()
+        cols = synthetic_columns(cfg["seed"], n)
+        polys = party_columns(cfg["seed"], cols, nparties)
+    tr = O.Transcript(b"cozk-spartan")
+    proof = prove_full(uniform, cross, padded, polys, n, tr)
+    vt = O.Transcript(b"cozk-spartan")
+    v = verify_full(proof, uniform, cross, padded, len(cols), n, vt)
+    ok = bool(v)
+    if ok:
+        rx_step, shift_r = v
+        for point, claims in ((rx_step, proof["witness_evals"]), (shift_r, proof["shift_witness_evals"])):
+            eq = O.eq_evals(point)
+            ok = ok and [sum(a * b for a, b in zip(eq, c)) % R for c in cols] == claims
+    blob = serialize_full(proof)
+    return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": ok, "proof": proof}

@@ -109,3 +109,91 @@ def test_large_verifies_and_rep3_equals_plain(cozk, log_steps):
         digs[mode] = bytes(r.proof_digest)
         h.close()
     assert digs["plain"] == digs["rep3"]
+
+
+# ------------------------------------------------------------------------------------------------ the whole Spartan worker
+def test_eq_plus_one_evals_match_the_oracle(cozk, ctx):
+    """cozk_eq_plus_one_evals == the oracle's table; the table is the indicator of y = x + 1 on Boolean x (no wrap-around)"""
+    P = importlib.import_module("co-zkvms_amd.poly")
+    rng = O.SplitMix64(5)
+    for l in (0, 1, 2, 5, 9):
+        r = [rng.field() for _ in range(l)]
+        got = P.eq_plus_one_evals(ctx, r).to_ints()
+        assert got == S.eq_plus_one_evals(r)[1]
+    for x in range(8):
+        bits = [(x >> (2 - j)) & 1 for j in range(3)]
+        tab = P.eq_plus_one_evals(ctx, bits).to_ints()
+        assert tab == [1 if (y == x + 1) else 0 for y in range(8)]
+        assert all(S.eq_plus_one_point(bits, [(y >> (2 - j)) & 1 for j in range(3)]) == tab[y] for y in range(8))
+
+
+@pytest.mark.parametrize("n", [1, 2, 64, 1000 + 24])
+def test_batch_dot_public_matches_dot_product_with_public(cozk, ctx, n):
+    """one pass over k polynomials x 2 public vectors == k x 2 calls of dot_product_with_public == the oracle; a plain
+    (public) polynomial in the batch gives a public value (b = 0)"""
+    P = importlib.import_module("co-zkvms_amd.poly")
+    rng = O.SplitMix64(n)
+    cols = [[(rng.field(), rng.field()) for _ in range(n)] for _ in range(3)] + [[rng.field() for _ in range(n)] for _ in range(2)]
+    pubs = [[rng.field() for _ in range(n)] for _ in range(2)]
+    dp = [cozk.Rep3DensePolynomial.new(ctx, c) for c in cols]
+    dv = [cozk.Vec.from_ints(ctx, p) for p in pubs]
+    for nq in (1, 2):
+        got = P.batch_dot_public(dp, dv[:nq])
+        for i, c in enumerate(cols):
+            for q in range(nq):
+                if isinstance(c[0], tuple):
+                    want = (sum(x[0] * w for x, w in zip(c, pubs[q])) % R, sum(x[1] * w for x, w in zip(c, pubs[q])) % R)
+                    assert dp[i].dot_product_with_public(dv[q]) == want
+                else:
+                    want = (sum(x * w for x, w in zip(c, pubs[q])) % R, 0)
+                assert got[i][q] == want
+
+
+@pytest.mark.parametrize("mode", ["plain", "rep3"])
+@pytest.mark.parametrize("system,log_steps,seed", [("jolt", 0, 3), ("jolt", 1, 5), ("jolt", 3, 5), ("jolt", 5, 7), ("toy", 2, 9), ("toy", 4, 4)])
+def test_whole_spartan_worker_bit_identical_to_the_oracle(cozk, mode, system, log_steps, seed):
+    """Rep3UniformSpartanProver::prove (outer + inner + shift sumchecks, the two claim exchanges) on the reference's own
+    constraint set: proof bytes == oracle/pyspartan_outer.py run_full, verified by the harness's own plain verifier"""
+    OU = importlib.import_module("co-zkvms_amd.outer")
+    h = OU.OuterHarness(mode=mode, log_steps=log_steps, seed=seed, system=system, full=True)
+    res = h.prove(verify=True)
+    assert res.verified == 1, h.last_error()
+    ref = S.run_full(dict(mode=mode, log_steps=log_steps, seed=seed, system=system))
+    assert ref["verified"]
+    assert h.proof_bytes(res) == ref["proof_bytes"]
+    h.close()
+
+
+@pytest.mark.parametrize("log_steps", [0, 2, 6])
+def test_jolt_system_outer_only_matches_the_oracle(cozk, log_steps):
+    """the outer sumcheck alone on the 128-rows-per-step system (the sparse oracle walks the same rows)"""
+    OU = importlib.import_module("co-zkvms_amd.outer")
+    import pyjolt_r1cs as J
+    for mode in ("plain", "rep3"):
+        h = OU.OuterHarness(mode=mode, log_steps=log_steps, seed=21, system="jolt")
+        res = h.prove(verify=True)
+        assert res.verified == 1, h.last_error()
+        n = 1 << log_steps
+        uniform, cross, padded = J.build_system()
+        cols = J.synthetic_columns(21, n)
+        polys = S.jolt_party_columns(21, cols, 1 if mode == "plain" else 3)
+        tr = O.Transcript(b"cozk-spartan-outer")
+        tau = tr.challenge_vector(log_steps + 7)
+        proof, _ = S.prove(uniform, cross, polys, padded, n, tau, tr)
+        blob = O.ser_u64(len(proof["round_polys"])) + b"".join(O.ser_vec_fr(c) for c in proof["round_polys"]) + O.ser_vec_fr(proof["claims"])
+        assert h.proof_bytes(res) == blob
+        h.close()
+
+
+@pytest.mark.parametrize("log_steps", [10, 14])
+def test_whole_spartan_worker_rep3_equals_plain(cozk, log_steps):
+    OU = importlib.import_module("co-zkvms_amd.outer")
+    digs = {}
+    for mode in ("plain", "rep3"):
+        h = OU.OuterHarness(mode=mode, log_steps=log_steps, seed=2026, system="jolt", full=True)
+        r = h.prove(verify=True)
+        assert r.verified == 1, h.last_error()
+        assert bytes(h.prove(verify=False).proof_digest) == bytes(r.proof_digest)
+        digs[mode] = bytes(r.proof_digest)
+        h.close()
+    assert digs["plain"] == digs["rep3"]
