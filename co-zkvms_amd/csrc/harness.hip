@@ -1067,3 +1067,4 @@ int cozk_worker_spartan_second_sumcheck(cozk_ctx* ctx, const cozk_worker_params*
 #include "host/spartan_harness.hpp"
 #include "host/lookups_harness.hpp"
 #include "host/outer_harness.hpp"
+#include "host/flow_harness.hpp"

@@ -742,6 +742,41 @@ int cozk_outer_harness_destroy(cozk_outer_harness* h);
 int cozk_outer_harness_prove(cozk_outer_harness* h, int verify, cozk_outer_result* res);
 int cozk_outer_harness_proof_bytes(const cozk_outer_harness* h, uint8_t* out, size_t cap);
 
+/* ---- ONE chained co-jolt worker flow (JoltRep3Prover::prove, co-jolt/src/jolt/vm/jolt/worker.rs:175-266, against its coordinator
+ * jolt/vm/jolt/coordinator.rs:118-222): commit-all -> bytecode memory checking -> instruction lookups (primary sumcheck, toggled
+ * read / write + dense init / final grand products) -> read-write memory checking + output check -> Spartan (outer + inner + shift) ->
+ * ONE reduce_and_prove over all accumulated openings; one transcript, one opening accumulator, all leaves K11 fingerprints of
+ * committed columns.  Synthetic Jolt-shaped witness (csrc/host/flow_harness.hpp); oracle/pyflow.py restates it. */
+typedef struct cozk_flow cozk_flow;
+typedef struct cozk_flow_config {
+    int mode;
+    int log_n;        /* trace length 2^log_n */
+    int log_m;        /* subtable / memory size M of the instruction lookups (Jolt: 16) */
+    int log_b;        /* bytecode size */
+    int log_mem;      /* read-write memory size */
+    int n_mem;        /* NUM_MEMORIES of the instruction lookups (Jolt RV32I: 54) */
+    int n_subtables;  /* Subtables::COUNT */
+    int devices[3];
+    uint64_t seed;
+    int precompute;   /* the SRS window table (cozk_bases_upload) */
+} cozk_flow_config;
+typedef struct cozk_flow_result {
+    int verified;
+    double wall_ms, t_commit_ms, t_bytecode_ms, t_primary_ms, t_lookups_gp_ms, t_rw_ms, t_spartan_ms, t_open_ms, t_worker_ms;
+    double t_spartan_build_ms;
+    uint64_t bytes_star_up, bytes_star_down, bytes_ring, star_messages;
+    uint64_t n_polys, n_openings;
+    uint64_t proof_len;
+    uint8_t proof_digest[32];
+} cozk_flow_result;
+int cozk_flow_create(const cozk_flow_config* cfg, cozk_flow** out);
+const char* cozk_flow_error(const cozk_flow* h);
+int cozk_flow_destroy(cozk_flow* h);
+size_t cozk_flow_num_polys(const cozk_flow* h);
+cozk_ctx* cozk_flow_ctx(cozk_flow* h, int party);
+int cozk_flow_prove(cozk_flow* h, int verify, cozk_flow_result* res);
+int cozk_flow_proof_bytes(const cozk_flow* h, uint8_t* out, size_t cap);
+
 /* ---------------------------------------------------------------- profiling ---------------- */
 /* HIP-event timing of the dominant kernel (MSM bucket accumulation, k_msm_accum0) on the ctx stream,
  * for bench.py's roofline object: launches, total ms, point additions issued, and the algorithmic

@@ -586,8 +586,9 @@ def receive_claims(parts, transcript):
     return claims, rho, batched
 
 
-def prove_full(uniform, cross, padded, polys_per_party, num_steps, transcript):
-    """the whole Rep3UniformSpartanProver::prove with its coordinator.  Returns the proof dict."""
+def prove_full(uniform, cross, padded, polys_per_party, num_steps, transcript, appends=None):
+    """the whole Rep3UniformSpartanProver::prove with its coordinator.  Returns the proof dict.  appends(point) -> claims: the
+    opening accumulator of a surrounding flow (oracle/pyflow.py); None: the two claim exchanges alone."""
     np_ = len(polys_per_party)
     nvars = len(polys_per_party[0])
     steps_bits = num_steps.bit_length() - 1
@@ -630,12 +631,16 @@ def prove_full(uniform, cross, padded, polys_per_party, num_steps, transcript):
         shift_claims.append(sum(sp_into_additive(sp_mul(a, b), p) for a, b in zip(zry, shift_polys[p][1])) % R)
     shift_claim = sum(shift_claims) % R  # combine_additive_share; NOT appended to the transcript (coordinator.rs:113-117)
     shift_comps, shift_r, _ = prove_arbitrary_mixed(shift_claims, steps_bits, shift_polys, transcript)
-    chis1 = O.eq_evals(rx_step)
-    parts = [_batch_evaluate_additive(polys_per_party[p], chis1, p) for p in range(np_)]
-    witness_evals, rho1, batched1 = receive_claims(parts, transcript)
-    chis2 = O.eq_evals(shift_r)
-    parts = [_batch_evaluate_additive(polys_per_party[p], chis2, p) for p in range(np_)]
-    shift_evals, rho2, batched2 = receive_claims(parts, transcript)
+    if appends is not None:
+        witness_evals, shift_evals = appends(rx_step), appends(shift_r)
+        rho1 = rho2 = batched1 = batched2 = None
+    else:
+        chis1 = O.eq_evals(rx_step)
+        parts = [_batch_evaluate_additive(polys_per_party[p], chis1, p) for p in range(np_)]
+        witness_evals, rho1, batched1 = receive_claims(parts, transcript)
+        chis2 = O.eq_evals(shift_r)
+        parts = [_batch_evaluate_additive(polys_per_party[p], chis2, p) for p in range(np_)]
+        shift_evals, rho2, batched2 = receive_claims(parts, transcript)
     return {"outer": outer, "outer_r": rs, "inner_polys": inner_comps, "inner_r": inner_r, "shift_claim": shift_claim, "shift_polys": shift_comps,
             "shift_r": shift_r, "witness_evals": witness_evals, "shift_witness_evals": shift_evals, "rlc": rlc, "tau": tau,
             "rho": [rho1, rho2], "batched": [batched1, batched2]}

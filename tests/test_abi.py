@@ -26,7 +26,7 @@ def test_header_symbols_exported(cozk):
     from importlib import import_module
     hp = import_module("co-zkvms_amd.harness")
     wk = import_module("co-zkvms_amd.workers")
-    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS + wk.WORKER_SYMBOLS + importlib.import_module("co-zkvms_amd.party_dist").PARTY_SYMBOLS + importlib.import_module("co-zkvms_amd.spartan").SPARTAN_SYMBOLS + importlib.import_module("co-zkvms_amd.lookups").LOOKUPS_SYMBOLS + importlib.import_module("co-zkvms_amd.outer").OUTER_SYMBOLS + importlib.import_module("co-zkvms_amd.logup").LOGUP_SYMBOLS:
+    for n in list(cozk._lib.SIGNATURES) + hp.HARNESS_SYMBOLS + wk.WORKER_SYMBOLS + importlib.import_module("co-zkvms_amd.party_dist").PARTY_SYMBOLS + importlib.import_module("co-zkvms_amd.spartan").SPARTAN_SYMBOLS + importlib.import_module("co-zkvms_amd.lookups").LOOKUPS_SYMBOLS + importlib.import_module("co-zkvms_amd.outer").OUTER_SYMBOLS + importlib.import_module("co-zkvms_amd.flow").FLOW_SYMBOLS + importlib.import_module("co-zkvms_amd.logup").LOGUP_SYMBOLS:
         assert n in names, n
 
 
