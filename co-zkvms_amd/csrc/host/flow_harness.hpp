@@ -20,6 +20,7 @@
 // independently of the R1CS LookupOutput column (a real trace identifies the two).  oracle/pyflow.py restates the flow; proofs are compared
 // byte for byte.
 #pragma once
+#include <functional>
 
 struct FlowIdx {
     int n_mem = 0;
@@ -69,6 +70,7 @@ struct cozk_flow {
     // the dealer's / verifier's clear view
     std::vector<std::vector<fe>> clear;  // per committed polynomial
     std::vector<int> is_public, pub_bytes;
+    std::vector<uint64_t> device_stream;  // != 0: the column is the seeded stream of this seed, generated on the device (no host copy)
     std::vector<size_t> lens;
     std::vector<std::vector<uint64_t>> bc_table_clear, subtables_clear;
     std::vector<fe> io_range_clear, v_io_clear;
@@ -156,6 +158,8 @@ void flow_build_clear(cozk_flow* h) {
     h->clear.assign((size_t)ix.count, {});
     h->is_public.assign((size_t)ix.count, 0);
     h->pub_bytes.assign((size_t)ix.count, 0);
+    h->device_stream.assign((size_t)ix.count, 0);
+    h->lens.assign((size_t)ix.count, 0);
     std::vector<std::vector<fe>> r1;
     jolt::build_clear(seed, N, r1);
     for (int v = 0; v < jolt::NUM_INPUTS; v++) {
@@ -170,10 +174,28 @@ void flow_build_clear(cozk_flow* h) {
         h->is_public[(size_t)idx] = 1;
         h->pub_bytes[(size_t)idx] = 4;
     };
+    // host threads over index ranges (the setup of a 2^20-cycle trace generates ~10^8 field elements)
+    auto par_for = [&](size_t n, const std::function<void(size_t, size_t)>& body) {
+        unsigned nt = std::thread::hardware_concurrency();
+        nt = nt == 0 ? 1 : (nt > 16 ? 16 : nt);
+        if (n < 4096 || nt == 1) {
+            body(0, n);
+            return;
+        }
+        std::vector<std::thread> ts;
+        for (unsigned k = 0; k < nt; k++) ts.emplace_back([&, k] { body(n * k / nt, n * (k + 1) / nt); });
+        for (auto& t : ts) t.join();
+    };
     auto sh = [&](int idx, uint64_t s, size_t n) {
         std::vector<fe>& col = h->clear[(size_t)idx];
         col.resize(n);
-        for (size_t i = 0; i < n; i++) col[i] = synthetic_fr_host(s, i);
+        par_for(n, [&](size_t lo, size_t hi) {
+            for (size_t i = lo; i < hi; i++) col[i] = synthetic_fr_host(s, i);
+        });
+    };
+    auto dev = [&](int idx, uint64_t s, size_t n) {
+        h->device_stream[(size_t)idx] = s;
+        h->lens[(size_t)idx] = n;
     };
     pub(ix.bc_t_read, 31, N, 20);
     pub(ix.bc_t_final, 32, B, 20);
@@ -182,9 +204,9 @@ void flow_build_clear(cozk_flow* h) {
     sh(ix.rw_v_final, seed + 46000, MEM);
     pub(ix.rw_t_final, 47, MEM, 20);
     for (int m = 0; m < c.n_mem; m++) {
-        sh(ix.read_cts + m, seed + 11000ull * (uint64_t)(m + 1), N);
+        dev(ix.read_cts + m, seed + 11000ull * (uint64_t)(m + 1), N);
         sh(ix.E + m, seed + 9000ull * (uint64_t)(m + 1), N);
-        sh(ix.final_cts + m, seed + 13000ull * (uint64_t)(m + 1), M);
+        dev(ix.final_cts + m, seed + 13000ull * (uint64_t)(m + 1), M);
     }
     static const int tab_bits[6] = {20, 32, 6, 6, 6, 12};
     h->bc_table_clear.assign(6, std::vector<uint64_t>(B));
@@ -197,24 +219,26 @@ void flow_build_clear(cozk_flow* h) {
     h->instrs = lookups_instr_table(c.n_mem);
     std::vector<fe>& outs = h->clear[(size_t)ix.lasso_out];
     outs.assign(N, Fr::zero());
-    std::vector<fe> E((size_t)c.n_mem);
-    for (size_t t = 0; t < N; t++) {
-        for (int i = 0; i < jolt::N_INSTR; i++) {
-            if (Fr::is_zero(h->clear[(size_t)(jolt::V_INSTR + i)][t])) continue;
-            const cozk_primary_instr& in = h->instrs[(size_t)i];
-            for (int j = 0; j < in.n_mems; j++) E[(size_t)in.mems[j]] = h->clear[(size_t)(ix.E + in.mems[j])][t];
-            outs[t] = primary_g_plain(in, E);
-            break;
+    par_for(N, [&](size_t lo, size_t hi) {
+        std::vector<fe> E((size_t)c.n_mem);
+        for (size_t t = lo; t < hi; t++) {
+            for (int i = 0; i < jolt::N_INSTR; i++) {
+                if (Fr::is_zero(h->clear[(size_t)(jolt::V_INSTR + i)][t])) continue;
+                const cozk_primary_instr& in = h->instrs[(size_t)i];
+                for (int j = 0; j < in.n_mems; j++) E[(size_t)in.mems[j]] = h->clear[(size_t)(ix.E + in.mems[j])][t];
+                outs[t] = primary_g_plain(in, E);
+                break;
+            }
         }
-    }
+    });
     h->io_range_clear.assign(MEM, Fr::zero());
     h->v_io_clear.assign(MEM, Fr::zero());
     for (size_t i = MEM / 4; i < MEM / 2; i++) {
         h->io_range_clear[i] = Fr::one();
         h->v_io_clear[i] = h->clear[(size_t)ix.rw_v_final][i];
     }
-    h->lens.resize((size_t)ix.count);
-    for (int i = 0; i < ix.count; i++) h->lens[(size_t)i] = h->clear[(size_t)i].size();
+    for (int i = 0; i < ix.count; i++)
+        if (!h->device_stream[(size_t)i]) h->lens[(size_t)i] = h->clear[(size_t)i].size();
 }
 
 uint64_t flow_share_seed(const cozk_flow* h, int idx) {
@@ -250,6 +274,17 @@ void flow_setup_party(cozk_flow* h, FlowParty& ps) {
     for (int i = 0; i < c.log_n; i++) t[(size_t)i] = synthetic_fr_host(c.seed ^ 0x7A7A7A7Aull, (uint64_t)i);
     ps.setup = PST13::setup(ctx, t, c.precompute);
     for (int idx = 0; idx < h->ix.count; idx++) {
+        if (h->device_stream[(size_t)idx]) {  // a seeded stream: generated and shared on the device (harness.hip make_share_vectors)
+            VecH a, b;
+            make_share_vectors(ctx, h->lens[(size_t)idx], h->device_stream[(size_t)idx], ps.party, c.mode, a, b);
+            cozk_poly* p = nullptr;
+            rc_check(cozk_poly_create(ctx, c.mode, a.h, b.h, &p), ctx, "poly_create");
+            ps.polys.push_back(PolyH(p));
+            cozk_vec* view = nullptr;
+            rc_check(cozk_poly_share_view(ctx, p, 0, &view), ctx, "share_view");
+            ps.commit_vecs.push_back(VecH(view));
+            continue;
+        }
         const std::vector<fe>& col = h->clear[(size_t)idx];
         cozk_vec* pv = nullptr;
         rc_check(cozk_vec_upload(ctx, col.data(), col.size(), COZK_SCALAR_FR, &pv), ctx, "vec_upload(column)");

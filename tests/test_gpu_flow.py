@@ -59,3 +59,26 @@ def test_flow_jolt_shape_verifies_and_rep3_equals_plain(cozk, log_n, n_mem, n_su
         digs[mode] = bytes(r.proof_digest)
         h.close()
     assert digs["plain"] == digs["rep3"]
+
+
+def test_golden_round3_digests(cozk):
+    """tests/golden/round3_pipelines.json: the HIP harnesses give the committed digests of the whole Spartan worker and of the flow"""
+    import json
+    import os
+    G = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "round3_pipelines.json")))
+    FL = importlib.import_module("co-zkvms_amd.flow")
+    OU = importlib.import_module("co-zkvms_amd.outer")
+    for row in G["flow"]:
+        cfg = dict(row["cfg"])
+        h = FL.FlowHarness(**cfg)
+        res = h.prove(verify=True)
+        assert res.verified == 1, h.last_error()
+        assert bytes(res.proof_digest).hex() == row["digest"] and int(res.proof_len) == row["proof_len"]
+        h.close()
+    for row in G["spartan_full"]:
+        cfg = dict(row["cfg"])
+        h = OU.OuterHarness(mode=cfg["mode"], log_steps=cfg["log_steps"], seed=cfg["seed"], system=cfg.get("system", "jolt"), full=True)
+        res = h.prove(verify=True)
+        assert res.verified == 1, h.last_error()
+        assert bytes(res.proof_digest).hex() == row["digest"]
+        h.close()
