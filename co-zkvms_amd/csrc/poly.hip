@@ -12,6 +12,7 @@
 #include <string.h>
 #include "poly.hip.hpp"
 #include "prf.hip.hpp"
+#include "fr9.hip.hpp"
 
 static constexpr int PT = 256;      // threads per block
 static constexpr int MAXBLK = 2048; // grid cap for reducing kernels (>= 8 blocks per CU)
@@ -445,6 +446,93 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic(const fe* __restrict__ 
     if (threadIdx.x == 0) fe_store(partial + gridDim.x + blockIdx.x, s2);
     s3 = fr_block_sum(s3, sh4);
     if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, s3);
+}
+
+// ---- the layer kernels on the 9 x 29 multiplier (round 3, fr9.hip.hpp): same thread mapping and tails as k_layer_cubic /
+// k_layer_bind_cubic, every product on the fused 29-bit chains, additions lazy, one lambda-removing product per lane at the end.
+// terms of one output chunk: s_k += (l_k x r_k) e_k [E2 factor folded into the eq pair first] at X = 0, 2, 3
+template <int NC, int NESTED>
+static __device__ __forceinline__ void layer9_terms(const Sh9<NC>& l0, const Sh9<NC>& r0, const Sh9<NC>& l1, const Sh9<NC>& r1, const fe* __restrict__ E1,
+                                                    size_t E1_half, int e1_shift, const fe* __restrict__ E2, size_t c, f9& s0, f9& s2, f9& s3) {
+    f9 e0, e1;
+    if (NESTED) {
+        const size_t x2 = c >> e1_shift, x1 = c & (E1_half - 1);
+        const f9 sc = f9_from_fe(fe_load(E2 + x2));
+        e0 = fr9_mul(f9_from_fe(fe_load(E1 + 2 * x1)), sc);
+        e1 = fr9_mul(f9_from_fe(fe_load(E1 + 2 * x1 + 1)), sc);
+    } else {
+        e0 = f9_from_fe(fe_load(E2 + 2 * c));
+        e1 = f9_from_fe(fe_load(E2 + 2 * c + 1));
+    }
+    const f9 me = f9_norm(f9_sub(e1, FR9_C2, e0));  // e0, e1 < 1.01 r normalised: me < 3.01 r
+    const f9 e2 = fr9_add(e1, me), e3 = fr9_add(e2, me);  // limbs < 2^30, 1.5 * 2^30
+    const Sh9<NC> ml = sh9_diff<NC>(l1, l0), mr = sh9_diff<NC>(r1, r0);
+    const Sh9<NC> l2 = sh9_add_norm<NC>(l1, ml), r2 = sh9_add_norm<NC>(r1, mr);
+    const Sh9<NC> l3 = sh9_add_norm<NC>(l2, ml), r3 = sh9_add_norm<NC>(r2, mr);
+    s0 = f9_norm(fr9_add(s0, fr9_mul(e0, sh9_local_mul<NC>(l0, r0))));
+    s2 = f9_norm(fr9_add(s2, fr9_mul(e2, sh9_local_mul<NC>(l2, r2))));
+    s3 = f9_norm(fr9_add(s3, fr9_mul(e3, sh9_local_mul<NC>(l3, r3))));
+}
+// lane sums -> canonical R-form block sums in partial[k * gridDim.x + blockIdx.x]
+template <int NESTED>
+static __device__ __forceinline__ void layer9_finish(const f9& s0, const f9& s2, const f9& s3, fe* __restrict__ partial, fe* sh4) {
+    const f9 K = f9_const(NESTED ? FR9_K3 : FR9_K2);
+    fe v = fr_block_sum(fr9_to_canonical(fr9_mul(s0, K)), sh4);
+    if (threadIdx.x == 0) fe_store(partial + blockIdx.x, v);
+    v = fr_block_sum(fr9_to_canonical(fr9_mul(s2, K)), sh4);
+    if (threadIdx.x == 0) fe_store(partial + gridDim.x + blockIdx.x, v);
+    v = fr_block_sum(fr9_to_canonical(fr9_mul(s3, K)), sh4);
+    if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, v);
+}
+
+template <int NC, int NESTED>
+__global__ void __launch_bounds__(PT) k_layer_cubic9(const fe* __restrict__ a, const fe* __restrict__ b, size_t len, const fe* __restrict__ E1, size_t E1_half,
+                                                  const fe* __restrict__ E2, size_t E2_len, fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    size_t nch = (len + 3) / 4;
+    const size_t limit = NESTED ? E1_half * E2_len : E2_len / 2;
+    if (nch > limit) nch = limit;  // zip() stops at the shorter side
+    const int e1_shift = NESTED ? __ffsll((long long)E1_half) - 1 : 0;
+    f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
+    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch; c += (size_t)gridDim.x * PT) {
+        const Sh9<NC> l0 = sh9_load_or_zero<NC>(a, b, 4 * c, len), r0 = sh9_load_or_zero<NC>(a, b, 4 * c + 1, len);
+        const Sh9<NC> l1 = sh9_load_or_zero<NC>(a, b, 4 * c + 2, len), r1 = sh9_load_or_zero<NC>(a, b, 4 * c + 3, len);
+        layer9_terms<NC, NESTED>(l0, r0, l1, r1, E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+    }
+    layer9_finish<NESTED>(s0, s2, s3, partial, sh4);
+}
+
+template <int NC, int NESTED>
+__global__ void __launch_bounds__(PT) k_layer_bind_cubic9(const fe* __restrict__ ia, const fe* __restrict__ ib, fe* oa, fe* ob, size_t len_in, fe r5,
+                                                       const fe* __restrict__ E1, size_t E1_half, const fe* __restrict__ E2, size_t E2_len,
+                                                       fe* __restrict__ partial) {
+    __shared__ fe sh4[4];
+    const size_t nch_in = (len_in + 3) / 4;
+    const size_t len_out = 2 * nch_in;
+    const size_t nch_out = (len_out + 3) / 4;
+    const size_t limit = NESTED ? E1_half * E2_len : E2_len / 2;
+    const int e1_shift = NESTED ? __ffsll((long long)E1_half) - 1 : 0;
+    const f9 r9 = f9_from_fe(r5);
+    f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
+    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch_out; c += (size_t)gridDim.x * PT) {
+        Sh9<NC> v[4];
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const size_t ci = 2 * c + h;
+            if (ci < nch_in) {
+                const Sh9<NC> u0 = sh9_load_or_zero<NC>(ia, ib, 4 * ci, len_in), u1 = sh9_load_or_zero<NC>(ia, ib, 4 * ci + 1, len_in);
+                const Sh9<NC> u2 = sh9_load_or_zero<NC>(ia, ib, 4 * ci + 2, len_in), u3 = sh9_load_or_zero<NC>(ia, ib, 4 * ci + 3, len_in);
+                v[2 * h] = sh9_lerp<NC>(u0, u2, r9);
+                v[2 * h + 1] = sh9_lerp<NC>(u1, u3, r9);
+                sh9_store<NC>(oa, ob, 2 * ci, v[2 * h]);
+                sh9_store<NC>(oa, ob, 2 * ci + 1, v[2 * h + 1]);
+            } else {
+                for (int k = 0; k < NC; k++) v[2 * h].c[k] = v[2 * h + 1].c[k] = fr9_zero();
+            }
+        }
+        if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+    }
+    layer9_finish<NESTED>(s0, s2, s3, partial, sh4);
 }
 
 // One whole sumcheck round of a SMALL layer in a single one-workgroup launch: bind the layer and the split-eq
@@ -1889,7 +1977,16 @@ static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
     const fe* E1 = eq->E1[eq->c1];
     const fe* E2 = eq->E2[eq->c2];
     bool nested = eq->E1_len != 1;
-    if (l->mode == COZK_MODE_REP3) {
+    static const int f9_env = getenv("COZK_LAYER_F9") ? atoi(getenv("COZK_LAYER_F9")) : 1;
+    if (f9_env != 0 && (l->len + 3) / 4 >= 1024) {  // the 9 x 29 multiplier kernels (fr9.hip.hpp) for throughput-bound layers
+        if (l->mode == COZK_MODE_REP3) {
+            if (nested) k_layer_cubic9<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+            else k_layer_cubic9<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+        } else {
+            if (nested) k_layer_cubic9<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
+            else k_layer_cubic9<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+        }
+    } else if (l->mode == COZK_MODE_REP3) {
         if (nested) k_layer_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
         else k_layer_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
     } else {
@@ -1954,7 +2051,19 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
             // algorithmic bytes: the layer read once and its bound half written once (SURVEY 8d K3 + K4 fused), + the eq tables
             const uint64_t S = l->mode == COZK_MODE_REP3 ? 64 : 32;
             ProfScope prof(ctx, COZK_PROF_BIND_CUBIC, (uint64_t)l->len * S + (uint64_t)nout * S + (uint64_t)(e->E1_len + e->E2_len) * 32);
-            if (l->mode == COZK_MODE_REP3) {
+            // 9 x 29 multiplier kernels for layers large enough to be throughput-bound (COZK_LAYER_F9=0: the saturated kernels)
+            static const int f9_env = getenv("COZK_LAYER_F9") ? atoi(getenv("COZK_LAYER_F9")) : 1;
+            if (f9_env != 0 && nch_out >= 1024) {
+                fe r5 = rr;
+                for (int d = 0; d < 5; d++) r5 = Fr::dbl(r5);  // the challenge times 2^5 = 1 / lambda (fr9.hip.hpp)
+                if (l->mode == COZK_MODE_REP3) {
+                    if (nested) k_layer_bind_cubic9<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, r5, E1, e->E1_len / 2, E2, e->E2_len, partial);
+                    else k_layer_bind_cubic9<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, r5, E1, 0, E2, e->E2_len, partial);
+                } else {
+                    if (nested) k_layer_bind_cubic9<1, 1><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, r5, E1, e->E1_len / 2, E2, e->E2_len, partial);
+                    else k_layer_bind_cubic9<1, 0><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, r5, E1, 0, E2, e->E2_len, partial);
+                }
+            } else if (l->mode == COZK_MODE_REP3) {
                 if (nested) k_layer_bind_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
                 else k_layer_bind_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, 0, E2, e->E2_len, partial);
             } else {
