@@ -284,4 +284,161 @@ static inline void g1_scalar_mul(g1j* r, const g1a* p, const uint64_t s[4]) {
         }
     *r = acc;
 }
+
+/* ---------------------------------------------------------------- round 3: the CPU baseline's fast path (bench.py cpu_baseline).
+ * Fq product with the modulus as compile-time constants, fully unrolled "no-carry" CIOS (the optimisation arkworks applies to
+ * moduli whose top bit is clear, ark-ff montgomery_backend): per outer step one multiply-add row for a * b[i] and one for m * p,
+ * carries in 128-bit temporaries.  Same function as fp_mul(&FQ, ..); tests compare the two. */
+static inline void fq_mul_fast(fp* r, const fp* a, const fp* b) {
+    const uint64_t N0 = 0x3c208c16d87cfd47ull, N1 = 0x97816a916871ca8dull, N2 = 0xb85045b68181585dull, N3 = 0x30644e72e131a029ull;
+    const uint64_t INV = 0x87d20782e4866389ull;
+    const uint64_t a0 = a->l[0], a1 = a->l[1], a2 = a->l[2], a3 = a->l[3];
+    uint64_t t0 = 0, t1 = 0, t2 = 0, t3 = 0;
+#define FQ_ROW(bi)                                                     \
+    do {                                                               \
+        u128 c = (u128)a0 * (bi) + t0;                                 \
+        uint64_t m = (uint64_t)c * INV;                                \
+        u128 d = (u128)m * N0 + (uint64_t)c;                           \
+        c = (u128)a1 * (bi) + t1 + (uint64_t)(c >> 64);                \
+        d = (u128)m * N1 + (uint64_t)c + (uint64_t)(d >> 64);          \
+        t0 = (uint64_t)d;                                              \
+        c = (u128)a2 * (bi) + t2 + (uint64_t)(c >> 64);                \
+        d = (u128)m * N2 + (uint64_t)c + (uint64_t)(d >> 64);          \
+        t1 = (uint64_t)d;                                              \
+        c = (u128)a3 * (bi) + t3 + (uint64_t)(c >> 64);                \
+        d = (u128)m * N3 + (uint64_t)c + (uint64_t)(d >> 64);          \
+        t2 = (uint64_t)d;                                              \
+        t3 = (uint64_t)(c >> 64) + (uint64_t)(d >> 64);                \
+    } while (0)
+    FQ_ROW(b->l[0]);
+    FQ_ROW(b->l[1]);
+    FQ_ROW(b->l[2]);
+    FQ_ROW(b->l[3]);
+#undef FQ_ROW
+    uint64_t t[4] = {t0, t1, t2, t3};
+    if (fp_geq(t, FQ.mod)) fp_sub_mod_raw(t, FQ.mod);
+    memcpy(r->l, t, 32);
+}
+static inline void fq_sqr_fast(fp* r, const fp* a) { fq_mul_fast(r, a, a); }
+
+/* XYZZ coordinates (x = X / ZZ, y = Y / ZZZ, ZZ^3 = ZZZ^2; EFD "xyzz"): the mixed addition is 8M + 2S instead of the Jacobian
+ * 7M + 4S, the general one 12M + 2S; zz == 0 <=> identity */
+typedef struct { fp x, y, zz, zzz; } g1x;
+static inline void g1x_identity(g1x* p) { fp_zero(&p->x); fp_zero(&p->y); fp_zero(&p->zz); fp_zero(&p->zzz); }
+static inline void g1x_double_affine(g1x* r, const g1a* q) { /* dbl-2008-s-1 with ZZ1 = ZZZ1 = 1 */
+    fp u, v, w, s, m, t;
+    fp_dbl(&FQ, &u, &q->y);
+    fq_sqr_fast(&v, &u);
+    fq_mul_fast(&w, &u, &v);
+    fq_mul_fast(&s, &q->x, &v);
+    fq_sqr_fast(&m, &q->x);
+    fp_dbl(&FQ, &t, &m);
+    fp_add(&FQ, &m, &m, &t);
+    fq_sqr_fast(&r->x, &m);
+    fp_dbl(&FQ, &t, &s);
+    fp_sub(&FQ, &r->x, &r->x, &t);
+    fp_sub(&FQ, &t, &s, &r->x);
+    fq_mul_fast(&r->y, &m, &t);
+    fq_mul_fast(&t, &w, &q->y);
+    fp_sub(&FQ, &r->y, &r->y, &t);
+    r->zz = v;
+    r->zzz = w;
+}
+static inline void g1x_double(g1x* r, const g1x* p) { /* dbl-2008-s-1 */
+    if (fp_is_zero(&p->zz)) { *r = *p; return; }
+    fp u, v, w, s, m, t, x3, y3;
+    fp_dbl(&FQ, &u, &p->y);
+    fq_sqr_fast(&v, &u);
+    fq_mul_fast(&w, &u, &v);
+    fq_mul_fast(&s, &p->x, &v);
+    fq_sqr_fast(&m, &p->x);
+    fp_dbl(&FQ, &t, &m);
+    fp_add(&FQ, &m, &m, &t);
+    fq_sqr_fast(&x3, &m);
+    fp_dbl(&FQ, &t, &s);
+    fp_sub(&FQ, &x3, &x3, &t);
+    fp_sub(&FQ, &t, &s, &x3);
+    fq_mul_fast(&y3, &m, &t);
+    fq_mul_fast(&t, &w, &p->y);
+    fp_sub(&FQ, &y3, &y3, &t);
+    fq_mul_fast(&r->zz, &v, &p->zz);
+    fq_mul_fast(&r->zzz, &w, &p->zzz);
+    r->x = x3;
+    r->y = y3;
+}
+/* r = p + (qx, qy) (madd-2008-s); neg != 0 adds the negated point */
+static inline void g1x_add_affine(g1x* r, const g1x* p, const g1a* q, int neg) {
+    if (q->inf) { *r = *p; return; }
+    fp qy = q->y;
+    if (neg) fp_neg(&FQ, &qy, &q->y);
+    if (fp_is_zero(&p->zz)) { r->x = q->x; r->y = qy; fp_one(&FQ, &r->zz); fp_one(&FQ, &r->zzz); return; }
+    fp u2, s2, pp_, rr, PP, PPP, Q, t, x3, y3;
+    fq_mul_fast(&u2, &q->x, &p->zz);
+    fq_mul_fast(&s2, &qy, &p->zzz);
+    fp_sub(&FQ, &pp_, &u2, &p->x);
+    fp_sub(&FQ, &rr, &s2, &p->y);
+    if (fp_is_zero(&pp_)) {
+        if (fp_is_zero(&rr)) { g1a qq = *q; qq.y = qy; g1x_double_affine(r, &qq); return; }
+        g1x_identity(r);
+        return;
+    }
+    fq_sqr_fast(&PP, &pp_);
+    fq_mul_fast(&PPP, &pp_, &PP);
+    fq_mul_fast(&Q, &p->x, &PP);
+    fq_sqr_fast(&x3, &rr);
+    fp_sub(&FQ, &x3, &x3, &PPP);
+    fp_dbl(&FQ, &t, &Q);
+    fp_sub(&FQ, &x3, &x3, &t);
+    fp_sub(&FQ, &t, &Q, &x3);
+    fq_mul_fast(&y3, &rr, &t);
+    fq_mul_fast(&t, &p->y, &PPP);
+    fp_sub(&FQ, &y3, &y3, &t);
+    fq_mul_fast(&r->zz, &p->zz, &PP);
+    fq_mul_fast(&r->zzz, &p->zzz, &PPP);
+    r->x = x3;
+    r->y = y3;
+}
+static inline void g1x_add(g1x* r, const g1x* a, const g1x* b) { /* add-2008-s */
+    if (fp_is_zero(&a->zz)) { *r = *b; return; }
+    if (fp_is_zero(&b->zz)) { *r = *a; return; }
+    fp u1, u2, s1, s2, pp_, rr, PP, PPP, Q, t, x3, y3;
+    fq_mul_fast(&u1, &a->x, &b->zz);
+    fq_mul_fast(&u2, &b->x, &a->zz);
+    fq_mul_fast(&s1, &a->y, &b->zzz);
+    fq_mul_fast(&s2, &b->y, &a->zzz);
+    fp_sub(&FQ, &pp_, &u2, &u1);
+    fp_sub(&FQ, &rr, &s2, &s1);
+    if (fp_is_zero(&pp_)) {
+        if (fp_is_zero(&rr)) { g1x_double(r, a); return; }
+        g1x_identity(r);
+        return;
+    }
+    fq_sqr_fast(&PP, &pp_);
+    fq_mul_fast(&PPP, &pp_, &PP);
+    fq_mul_fast(&Q, &u1, &PP);
+    fq_sqr_fast(&x3, &rr);
+    fp_sub(&FQ, &x3, &x3, &PPP);
+    fp_dbl(&FQ, &t, &Q);
+    fp_sub(&FQ, &x3, &x3, &t);
+    fp_sub(&FQ, &t, &Q, &x3);
+    fq_mul_fast(&y3, &rr, &t);
+    fq_mul_fast(&t, &s1, &PPP);
+    fp_sub(&FQ, &y3, &y3, &t);
+    fq_mul_fast(&t, &a->zz, &b->zz);
+    fq_mul_fast(&r->zz, &t, &PP);
+    fq_mul_fast(&t, &a->zzz, &b->zzz);
+    fq_mul_fast(&r->zzz, &t, &PPP);
+    r->x = x3;
+    r->y = y3;
+}
+static inline void g1x_to_affine(g1a* r, const g1x* p) {
+    if (fp_is_zero(&p->zz)) { fp_zero(&r->x); fp_zero(&r->y); r->inf = 1; return; }
+    fp zi, zzi, t;
+    fp_inv(&FQ, &zi, &p->zzz);     /* 1 / ZZZ */
+    fq_mul_fast(&t, &zi, &p->zz);  /* ZZ / ZZZ = 1 / Z */
+    fq_sqr_fast(&zzi, &t);         /* 1 / ZZ */
+    fq_mul_fast(&r->x, &p->x, &zzi);
+    fq_mul_fast(&r->y, &p->y, &zi);
+    r->inf = 0;
+}
 #endif

@@ -30,8 +30,46 @@ void orc_fp_binop(int base_field, int op, const uint64_t* a, const uint64_t* b, 
         memcpy(out + 4 * i, r.l, 32);
     }
 }
+/* the cores this process may really use: the CPU affinity mask capped by the cgroup's CPU quota (a container on a 128-thread host
+ * with a 16-CPU share runs 16 threads' worth of work, and 128 OpenMP threads only fight over them) */
+static int effective_cpus(void) {
+    int n = 0;
+#ifdef _OPENMP
+    n = omp_get_num_procs();
+#endif
+    if (n < 1) n = 1;
+    FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64];
+        long long period = 0;
+        if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+            long long quota = atoll(q);
+            int c = (int)((quota + period - 1) / period);
+            if (c >= 1 && c < n) n = c;
+        }
+        fclose(f);
+    }
+    const char* e = getenv("ORC_THREADS");
+    if (e && atoi(e) >= 1) n = atoi(e);
+    return n;
+}
+/* test hook: the fast Fq product (bn254.h fq_mul_fast) -- tests/test_oracle.py compares it with fp_mul and the Python oracle */
+void orc_fq_mul_fast(const uint64_t* a, const uint64_t* b, uint64_t* out, size_t n) {
+    for (size_t i = 0; i < n; i++) {
+        fp x, y, r;
+        memcpy(x.l, a + 4 * i, 32);
+        memcpy(y.l, b + 4 * i, 32);
+        fq_mul_fast(&r, &x, &y);
+        memcpy(out + 4 * i, r.l, 32);
+    }
+}
 int orc_num_threads(void) {
 #ifdef _OPENMP
+    static int set = 0;
+    if (!set) {
+        omp_set_num_threads(effective_cpus());
+        set = 1;
+    }
     return omp_get_max_threads();
 #else
     return 1;
@@ -75,38 +113,34 @@ static void msm_core(const g1a* bases, const uint64_t* scalars, size_t n, int nb
             digits[i * nwin + w] = (int32_t)d;
         }
     }
-    g1j* wsum = (g1j*)malloc(sizeof(g1j) * nwin);
+    g1x* wsum = (g1x*)malloc(sizeof(g1x) * nwin);
     size_t nb = (size_t)1 << (c - 1);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int w = 0; w < nwin; w++) {
-        g1j* buckets = (g1j*)malloc(sizeof(g1j) * nb);
-        for (size_t b = 0; b < nb; b++) g1j_identity(&buckets[b]);
+        g1x* buckets = (g1x*)malloc(sizeof(g1x) * nb);
+        for (size_t b = 0; b < nb; b++) g1x_identity(&buckets[b]);
         for (size_t i = 0; i < n; i++) {
             int32_t d = digits[i * nwin + w];
-            if (d > 0) g1j_add_affine(&buckets[d - 1], &buckets[d - 1], &bases[i]);
-            else if (d < 0) {
-                g1a ng;
-                g1a_neg(&ng, &bases[i]);
-                g1j_add_affine(&buckets[-d - 1], &buckets[-d - 1], &ng);
-            }
+            if (d > 0) g1x_add_affine(&buckets[d - 1], &buckets[d - 1], &bases[i], 0);
+            else if (d < 0) g1x_add_affine(&buckets[-d - 1], &buckets[-d - 1], &bases[i], 1);
         }
-        g1j run, acc;
-        g1j_identity(&run);
-        g1j_identity(&acc);
+        g1x run, acc;
+        g1x_identity(&run);
+        g1x_identity(&acc);
         for (size_t b = nb; b-- > 0;) {
-            g1j_add(&run, &run, &buckets[b]);
-            g1j_add(&acc, &acc, &run);
+            g1x_add(&run, &run, &buckets[b]);
+            g1x_add(&acc, &acc, &run);
         }
         wsum[w] = acc;
         free(buckets);
     }
-    g1j total;
-    g1j_identity(&total);
+    g1x total;
+    g1x_identity(&total);
     for (int w = nwin - 1; w >= 0; w--) {
-        for (int k = 0; k < c; k++) g1j_double(&total, &total);
-        g1j_add(&total, &total, &wsum[w]);
+        for (int k = 0; k < c; k++) g1x_double(&total, &total);
+        g1x_add(&total, &total, &wsum[w]);
     }
-    g1j_to_affine(out, &total);
+    g1x_to_affine(out, &total);
     free(wsum);
     free(digits);
 }
@@ -120,6 +154,7 @@ static void load_bases(const uint64_t* xy, const uint8_t* inf, size_t n, g1a* ou
 }
 /* scalars_mont: Fr Montgomery limbs (arkworks layout) */
 void orc_msm(const uint64_t* xy, const uint8_t* inf, const uint64_t* scalars_mont, size_t n, uint64_t* out_xy, int* out_inf) {
+    (void)orc_num_threads();
     g1a* bases = (g1a*)malloc(sizeof(g1a) * (n ? n : 1));
     load_bases(xy, inf, n, bases);
     uint64_t* sc = (uint64_t*)malloc(32 * (n ? n : 1));

@@ -68,6 +68,16 @@ def fp_binop(base_field, op, a, b):
     return out
 
 
+def fq_mul_fast(a, b):
+    """the CPU baseline's unrolled Fq product (oracle/c/bn254.h fq_mul_fast) on (n, 4) Montgomery limb arrays"""
+    import numpy as np
+    a = np.ascontiguousarray(a, dtype=np.uint64)
+    b = np.ascontiguousarray(b, dtype=np.uint64)
+    out = np.empty_like(a)
+    lib().orc_fq_mul_fast(a.ctypes.data_as(ctypes.c_void_p), b.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.shape[0]))
+    return out
+
+
 def msm(xy, inf, scalars_mont):
     import numpy as np
     xy = np.ascontiguousarray(xy, dtype=np.uint64)

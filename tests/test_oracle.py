@@ -111,6 +111,29 @@ def test_c_field_ops_against_golden(field):
         assert got == [int(r[key], 16) for r in rows]
 
 
+def test_c_fast_fq_product_and_xyzz_msm():
+    """round 3 CPU baseline: the unrolled no-carry Fq product == the textbook CIOS == the golden products (edge operands 0, 1,
+    p - 1, R, >= 2^253 included); the XYZZ Pippenger (now orc_msm's path) on repeated bases / infinity / cancelling points"""
+    rows = GOLD["fq"]
+    a = [int(r["a"], 16) for r in rows] + [0, 1, O.P - 1, O.P - 1, (1 << 253) + 7]
+    b = [int(r["b"], 16) for r in rows] + [5, O.P - 1, O.P - 1, 1, O.P - 2]
+    A, B = _limbs(a, O.P), _limbs(b, O.P)
+    got = _ints(coracle.fq_mul_fast(A, B), O.P)
+    assert got == [x * y % O.P for x, y in zip(a, b)]
+    assert got == _ints(coracle.fp_binop(1, 2, A, B), O.P)
+    rng = O.SplitMix64(99)
+    g = O.G1_GEN
+    base = [O.g1_mul(g, rng.field()) for _ in range(5)]
+    pts = base + [base[0], O.g1_neg(base[1]), base[2], base[2]] + [(0, 0)]
+    inf = np.array([0] * 9 + [1], dtype=np.uint8)
+    sc = [rng.field() for _ in range(5)] + [3, 3, O.R - 1, 1, 12345]
+    sc[6] = sc[1]  # s * P + s * (-P) cancels inside one bucket
+    xy = np.concatenate([_limbs([p[0] for p in pts], O.P), _limbs([p[1] for p in pts], O.P)], axis=1)
+    out, oinf = coracle.msm(xy, inf, _limbs(sc, O.R))
+    want = O.msm_naive([None if i == 9 else p for i, p in enumerate(pts)], sc)
+    assert oinf == 0 and (_ints([out[:4]], O.P)[0], _ints([out[4:]], O.P)[0]) == want
+
+
 def test_gkr_and_pst_identities_small():
     rng = O.SplitMix64(9)
     leaves = [rng.field() for _ in range(32)]
