@@ -155,9 +155,24 @@ def run_plumbing(args):
     grp.barrier()
     t = grp.max_over_ranks(1.0 + grp.rank)
     digs = grp.all_gather_bytes(bytes([grp.rank]) * 32)
+    # the star exchange of a worker-sharded proof: libcozk's shared-memory hub (host-only code, needs no GPU), 64 rounds of a few
+    # hundred bytes from every rank, each rank checking every other rank's bytes of every round
+    hub_ok = None
+    if args.hub == "shm":
+        pd = importlib.import_module("co-zkvms_amd.party_dist")
+        hub = pd.ShmHub(grp.rank, grp.world, grp.cpu_group())
+        hub_ok = True
+        for rnd in range(64):
+            got = hub.all_gather(bytes([(grp.rank * 31 + rnd + k) & 0xFF for k in range(136 + grp.rank)]), cap=4096)
+            for q in range(grp.world):
+                hub_ok = hub_ok and got[q] == bytes([(q * 31 + rnd + k) & 0xFF for k in range(136 + q)])
+        oks = grp.all_gather_bytes(bytes([1 if hub_ok else 0]) * 32)
+        hub_ok = all(o[0] == 1 for o in oks)
+        hub.close()
     grp.barrier()
     if grp.rank == 0:
-        print(json.dumps({"plumbing_only": True, "n_gpus": grp.world, "max_over_ranks": t, "ranks_seen": [d[0] for d in digs]}), flush=True)
+        print(json.dumps({"plumbing_only": True, "n_gpus": grp.world, "max_over_ranks": t, "ranks_seen": [d[0] for d in digs],
+                          "shm_hub_64_rounds_ok": hub_ok}), flush=True)
     grp.close()
 
 
@@ -244,8 +259,11 @@ def run_rank(args):
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     phases = dict(commit=0.0, gp_construct=0.0, gp_prove=0.0, evaluate=0.0, open=0.0)
+    hub_wait_ms, hub_exchanges = 0.0, 0
     for _ in range(args.steps):
         r = h.prove(verify=False)
+        hub_wait_ms += getattr(r, "t_hub_wait_ms", 0.0)
+        hub_exchanges += int(getattr(r, "hub_exchanges", 0))
         phases["commit"] += r.t_commit_ms
         phases["gp_construct"] += r.t_gp_construct_ms
         phases["gp_prove"] += r.t_gp_prove_ms
@@ -267,11 +285,18 @@ def run_rank(args):
     torch.cuda.synchronize(dev)
     grp.barrier()
     dt = time.perf_counter() - t0
+    dt_local = dt
     dt = grp.max_over_ranks(dt)
     prof = hprof.prof_read(h, 0)
     kprof = hprof.prof_read_kernels(h, 0)
     hprof.prof_enable(h, 0, False)
     digests = grp.all_gather_bytes(digest0)
+    # per-rank view (N > 1): every rank's phase times and the time its coordinator copy waited in the hub for the slowest participant
+    # of each star exchange -- what makes a scaling curve interpretable (a rank that waits is not the one that limits the step)
+    mine = json.dumps({"rank": rank, "device": dev, "ms_per_step": round(dt_local * 1e3 / args.steps, 3),
+                       "phases_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()},
+                       "hub_wait_ms_per_step": round(hub_wait_ms / args.steps, 3), "hub_exchanges_per_step": hub_exchanges // max(1, args.steps)}).encode()
+    per_rank = [json.loads(b.rstrip(b"\0").decode()) for b in grp.all_gather_bytes(mine.ljust(1024, b"\0"), width=1024)] if world > 1 else None
 
     cycles = (1 << log_n) * args.steps * world
     value = cycles / dt
@@ -357,6 +382,8 @@ def run_rank(args):
            "phases_ms_per_step": {k: round(v / args.steps, 3) for k, v in phases.items()},
            "setup_s": round(t_setup, 2), "proof_bytes": int(res.proof_len), "proof_sha256": [d.hex()[:16] for d in digests],
            "roofline": roofline}
+    if per_rank is not None:
+        out["per_rank"] = per_rank
 
     # ---- host-resident witness: what the H2D leg adds when the boundary hands over host buffers (never part of `value`)
     if args.host_witness and rank == 0 and world == 1:

@@ -833,6 +833,8 @@ struct HubStarCoordinator : StarNetCoordinator {
     int me;
     std::unique_ptr<uint8_t[]> recv_buf;  // n x 256 KiB landing slots, allocated once (rounds are ~1 us apart)
     std::vector<size_t> lens;
+    double t_wait_ms = 0;   // time inside the hub's all_gather (= waiting for the slowest participant of each exchange)
+    uint64_t n_exchanges = 0;
     HubStarCoordinator(InProcStar* l, const cozk_hub_net& h, int me_) : local(l), hub(h), me(me_) {}
     std::vector<Bytes> gather(const Bytes& mine) {
         const size_t cap = 1 << 18;
@@ -840,8 +842,11 @@ struct HubStarCoordinator : StarNetCoordinator {
         uint8_t* recv = recv_buf.get();
         lens.assign((size_t)hub.n_participants, 0);
         if (mine.size() > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: message larger than the 256 KiB slot");
+        const double tw0 = now_ms();
         if (hub.all_gather(hub.user, mine.data(), mine.size(), recv, cap, lens.data()) != 0)
             throw CozkError(COZK_ERR_INTERNAL, "hub all_gather callback failed");
+        t_wait_ms += now_ms() - tw0;
+        n_exchanges++;
         std::vector<Bytes> out;
         for (int p = 0; p < hub.n_participants; p++) {
             if (lens[p] > cap) throw CozkError(COZK_ERR_INTERNAL, "hub all_gather: bad length");
@@ -891,9 +896,13 @@ int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, con
     std::string why;
     int verified = -1;
     int rc = COZK_OK;
+    double hub_wait = 0;
+    uint64_t hub_n = 0;
     try {
         HubStarCoordinator coord(&star, *hub, me);
         verified = W > 1 ? coordinator_main_split(h, coord, proof, verify != 0, why) : coordinator_main(h, coord, proof, verify != 0, why);
+        hub_wait = coord.t_wait_ms;
+        hub_n = coord.n_exchanges;
     } catch (const std::exception& e) {
         h->error = std::string("coordinator: ") + e.what();
         star.abort.flag.store(true);
@@ -919,6 +928,8 @@ int cozk_harness_prove_distributed(cozk_harness* h, const cozk_hub_net* hub, con
     res->bytes_star_down = ps.star_down;
     res->bytes_ring = ps.ring_bytes;
     res->star_messages = ps.star_msgs;
+    res->t_hub_wait_ms = hub_wait;
+    res->hub_exchanges = hub_n;
     h->last_proof = proof.serialize();
     res->proof_len = h->last_proof.size();
     Sha256 s;

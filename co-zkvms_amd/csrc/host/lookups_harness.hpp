@@ -103,6 +103,20 @@ std::vector<cozk_primary_instr> lookups_instr_table(int n_mem) {
     return out;
 }
 
+// cfg.mix = 1: a trace-shaped instruction mix -- the proportions of a sha2-chain guest (the reference's benchmark program,
+// co-jolt/README.md:20-31): per 256 cycles, in the order of jolt/vm/rv32i_vm.rs:41-70.  ADD (address arithmetic and the loads /
+// stores' lookups), XOR, AND, OR, SLL, SRL dominate; 15 of 256 cycles (6 %) run a multiplicative collation against 37 % uniformly.
+static const uint8_t LOOKUPS_SHA2_MIX[27] = {72, 4, 20, 20, 56, 2, 1, 1, 3, 1, 6, 24, 2, 30, 1, 1, 1, 1, 2, 4, 1, 0, 0, 0, 2, 1, 0};
+static inline int lookups_mix_instr(int mix, uint32_t byte) {
+    if (mix == 0) return (int)(byte % 27);
+    uint32_t acc = 0;
+    for (int i = 0; i < 27; i++) {
+        acc += LOOKUPS_SHA2_MIX[i];
+        if (byte < acc) return i;
+    }
+    return 0;
+}
+
 // the dealer's view: which instruction every cycle runs and lookup_outputs(x) = g_{which(x)}(E(x)) in the clear
 void lookups_setup_primary_clear(cozk_lookups* h) {
     const cozk_lookups_config& c = h->cfg;
@@ -111,7 +125,7 @@ void lookups_setup_primary_clear(cozk_lookups* h) {
     h->outputs_plain.resize(h->N);
     std::vector<fe> E((size_t)c.n_pairs);
     for (size_t x = 0; x < h->N; x++) {
-        uint8_t w = (uint8_t)(synthetic_small_host(c.seed + 1234567ull, x, 8) % h->instrs.size());
+        uint8_t w = (uint8_t)lookups_mix_instr(c.mix, synthetic_small_host(c.seed + 1234567ull, x, 8));
         h->which[x] = w;
         const cozk_primary_instr& in = h->instrs[w];
         for (int t = 0; t < in.n_mems; t++) E[in.mems[t]] = synthetic_fr_host(c.seed + 9000ull * (uint64_t)(in.mems[t] + 1), x);
@@ -549,6 +563,7 @@ int cozk_lookups_create(const cozk_lookups_config* cfg, cozk_lookups** out) {
         COZK_REQUIRE(cfg->log_workers >= 0 && cfg->log_workers <= 3 && cfg->log_workers < cfg->log_n, "lookups: log_workers in 0..3, below log_n");
         COZK_REQUIRE(cfg->log_n >= 1 && cfg->log_n <= 24 && cfg->n_pairs >= 1 && cfg->n_pairs <= 128 && cfg->density_pct >= 0 && cfg->density_pct <= 100,
                      "lookups: log_n in 1..24, n_pairs in 1..128, density_pct in 0..100");
+        COZK_REQUIRE(cfg->mix == 0 || cfg->mix == 1, "lookups: mix is 0 (uniform) or 1 (sha2-shaped)");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->N = (size_t)1 << cfg->log_n;
         h->batch = 2 * (size_t)cfg->n_pairs;

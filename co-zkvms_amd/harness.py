@@ -20,7 +20,8 @@ class HarnessResult(ctypes.Structure):
                 ("t_gp_construct_ms", ctypes.c_double), ("t_gp_prove_ms", ctypes.c_double), ("t_eval_ms", ctypes.c_double),
                 ("t_open_ms", ctypes.c_double), ("t_worker_ms", ctypes.c_double), ("bytes_star_up", ctypes.c_uint64),
                 ("bytes_star_down", ctypes.c_uint64), ("bytes_ring", ctypes.c_uint64), ("star_messages", ctypes.c_uint64),
-                ("proof_len", ctypes.c_uint64), ("proof_digest", ctypes.c_uint8 * 32)]
+                ("proof_len", ctypes.c_uint64), ("proof_digest", ctypes.c_uint8 * 32), ("t_hub_wait_ms", ctypes.c_double),
+                ("hub_exchanges", ctypes.c_uint64)]
 
 
 _declared = False

@@ -12,7 +12,7 @@ from .engine import Vec, fr_to_mont_limbs, mont_limbs_to_int
 
 class LookupsConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("n_pairs", ctypes.c_int), ("density_pct", ctypes.c_int),
-                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64), ("log_workers", ctypes.c_int), ("primary", ctypes.c_int)]
+                ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64), ("log_workers", ctypes.c_int), ("primary", ctypes.c_int), ("mix", ctypes.c_int)]
 
 
 class LookupsResult(ctypes.Structure):
@@ -64,9 +64,10 @@ def _decl():
 
 
 class LookupsHarness:
-    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1, primary=False, log_workers=0):
+    def __init__(self, mode="plain", log_n=6, n_pairs=2, density_pct=25, devices=(0, 0, 0), seed=1, primary=False, log_workers=0, mix="uniform"):
         self._l = _decl()
         cfg = LookupsConfig()
+        cfg.mix = 1 if mix == "sha2" else 0
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
         cfg.log_n, cfg.n_pairs, cfg.density_pct = log_n, n_pairs, density_pct
         cfg.devices = (ctypes.c_int * 3)(*devices)

@@ -603,6 +603,9 @@ typedef struct cozk_harness_result {
     uint64_t bytes_star_up, bytes_star_down, bytes_ring, star_messages;
     uint64_t proof_len;
     uint8_t proof_digest[32]; /* SHA-256 of the serialized proof */
+    double t_hub_wait_ms;     /* cozk_harness_prove_distributed: time this participant's coordinator copy spent inside the hub's
+                               * all_gather (waiting for the slowest participant of every star exchange); 0 in-process */
+    uint64_t hub_exchanges;
 } cozk_harness_result;
 int cozk_harness_create(const cozk_harness_config* cfg, cozk_harness** out);
 const char* cozk_harness_error(const cozk_harness* h);
@@ -699,6 +702,9 @@ typedef struct cozk_lookups_config {
                         workers of a party are time-sliced on its context here (one GPU each in a real deployment) */
     int primary; /* 1: run Lasso's primary sumcheck first (n_pairs E polynomials, a five-instruction synthetic table of the
                     three collation forms, lookup_outputs = sum_i flag_i g_i(E)); the proof then starts with its part */
+    int mix;     /* instruction mix of the synthetic trace: 0 = uniform over the 27 RV32I instructions (37 % of the cycles run a
+                    multiplicative collation); 1 = trace-shaped, the proportions of a sha2-chain guest (ADD / XOR / AND / OR / SLL /
+                    SRL dominant, ~6 % multiplicative; csrc/host/lookups_harness.hpp LOOKUPS_SHA2_MIX) */
 } cozk_lookups_config;
 typedef struct cozk_lookups_result {
     int verified; /* 1 ok, 0 rejected, -1 not run */

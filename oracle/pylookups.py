@@ -46,6 +46,20 @@ def instr_table(n_mem):
     return [P.Instr(form, [(3 * t + (0 if rep else j)) % n_mem for j in range(n)], bits) for t, (form, n, bits, rep) in enumerate(rows)]
 
 
+SHA2_MIX = [72, 4, 20, 20, 56, 2, 1, 1, 3, 1, 6, 24, 2, 30, 1, 1, 1, 1, 2, 4, 1, 0, 0, 0, 2, 1, 0]  # lookups_harness.hpp LOOKUPS_SHA2_MIX: cycles per 256 of each RV32I instruction in a sha2-chain-shaped trace
+
+
+def mix_instr(mix, byte):
+    if not mix:
+        return byte % 27
+    acc = 0
+    for i, c in enumerate(SHA2_MIX):
+        acc += c
+        if byte < acc:
+            return i
+    return 0
+
+
 def run_primary(cfg, tr, vt):
     """the primary-sumcheck phase: returns (serialized part, verified)"""
     nparties = 1 if cfg["mode"] == "plain" else 3
@@ -53,7 +67,7 @@ def run_primary(cfg, tr, vt):
     n_mem = cfg["n_pairs"]
     seed = cfg["seed"]
     instrs = instr_table(n_mem)
-    which = [v % len(instrs) for v in O.synthetic_small(seed + 1234567, n, 8)]
+    which = [mix_instr(cfg.get("mix", 0), v) for v in O.synthetic_small(seed + 1234567, n, 8)]
     flags = [[1 if which[x] == i else 0 for x in range(n)] for i in range(len(instrs))]
     Ep = [O.synthetic_fr(seed + 9000 * (m + 1), n) for m in range(n_mem)]
     out = [P.g_plain(instrs[which[x]], [Ep[m][x] for m in instrs[which[x]].mems]) for x in range(n)]

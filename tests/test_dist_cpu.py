@@ -80,6 +80,22 @@ def test_bench_self_launch_one_late_rank_fails_fast():
     assert not [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
 
 
+def test_bench_self_launch_eight_ranks_cpu_rehearsal():
+    """the 8-rank shape of the driver's scaling run, rehearsed where it is allowed to run -- on the CPU (a GPU box admits
+    at most 6 processes on its card, so 8 GPU ranks are the driver's to start on an 8-GPU node): `bench.py --gpus 8` starts its 8
+    ranks itself, they rendezvous over gloo on 127.0.0.1, run the barrier / max-over-ranks / digest-gather plumbing of the timed
+    region and 64 rounds of the worker sub-nets' star exchange through libcozk's shared-memory hub, every rank checking every
+    other rank's bytes"""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--plumbing-only"], env=env, capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-2000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 8 and out["ranks_seen"] == list(range(8)) and out["max_over_ranks"] == 8.0 and out["shm_hub_64_rounds_ok"] is True
+
+
 def test_bench_rejects_world_size_mismatch():
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="2")
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--plumbing-only"], env=env, capture_output=True, timeout=120)

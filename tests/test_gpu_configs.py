@@ -58,11 +58,35 @@ def test_config3_spartan_2p18_rep3_equals_plain(cozk):
     assert digs["plain"] == digs["rep3"]
 
 
-def test_config4_substitute_8_worker_split_2p17(cozk):
-    """one proof of a 2^17-cycle trace as 8 worker sub-nets (the substitute for the Shamir configuration): verifies,
-    and its commitments + GKR part are the single-worker proof's (tests/test_gpu_split.py checks the byte prefix)"""
-    h = cozk.Harness(mode="plain", log_n=17, n_fr=8, n_u16=4, n_u32=2, n_flags=2, n_small=0, gp_batch=8, gp_log_leaves=18, seed=2026,
+@pytest.mark.parametrize("log_n", [17, 21])
+def test_config4_substitute_8_worker_split(cozk, log_n):
+    """one proof of a 2^17- / 2^21-cycle trace as 8 worker sub-nets time-sliced on the one GPU (the substitute for the Shamir
+    configuration, whose 2^24 trace is 2^21 cycles per GPU on the 8-GPU node): verifies, and its commitments + GKR part are the
+    single-worker proof's (tests/test_gpu_split.py checks the byte prefix)"""
+    h = cozk.Harness(mode="plain", log_n=log_n, n_fr=8, n_u16=4, n_u32=2, n_flags=2, n_small=0, gp_batch=8, gp_log_leaves=log_n + 1, seed=2026,
                      log_workers=3)
     r = h.prove(verify=True)
     assert r.verified == 1, h.last_error()
+    assert bytes(h.prove(verify=False).proof_digest) == bytes(r.proof_digest)
     h.close()
+
+
+def test_bench_four_ranks_share_the_gpu():
+    """`bench.py --gpus 4 --log-n 14` starts its own four ranks (4 processes on the card: within the box's guard of 6; the 8-rank
+    run is the driver's, on an 8-GPU node -- tests/test_dist_cpu.py rehearses its launch and hub on the CPU): ONE proof of a
+    2^16-cycle trace as 4 worker sub-nets, one JSON line, every rank assembled the same proof, per-rank phases and hub waits"""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--log-n", "14", "--steps", "2", "--warmup", "1"], env=env,
+                       capture_output=True, timeout=600)
+    assert p.returncode == 0, p.stderr.decode()[-3000:]
+    lines = [ln for ln in p.stdout.decode().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 4 and out["scaling"] == "weak" and len(set(out["proof_sha256"])) == 1 and len(out["proof_sha256"]) == 4
+    assert [r["rank"] for r in out["per_rank"]] == [0, 1, 2, 3]
+    assert all(r["hub_exchanges_per_step"] > 0 and r["hub_wait_ms_per_step"] >= 0 for r in out["per_rank"])

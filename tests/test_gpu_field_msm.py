@@ -199,6 +199,24 @@ def test_rep3_scatter_device_to_device(cozk, ctx):
         party_ctx.close()
 
 
+def test_rep3_scatter_peer_copy_two_gpus(cozk, ctx):
+    """the hipMemcpyPeer leg of cozk_rep3_scatter (dealer on GPU 0, party on GPU 1): skipped on this pool's 1-GPU boxes"""
+    import torch
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs")
+    n = 1 << 16
+    V = cozk.Vec.random(ctx, n, seed=31)
+    k0, k1 = O.harness_prf_key(71, 0), O.harness_prf_key(72, 0)
+    party_ctx = cozk.Context(1)
+    for p in range(3):
+        a, b = V.rep3_scatter(k0, k1, p, party_ctx, counter=7)
+        ea, eb = V.rep3_share(k0, k1, p, counter=7)
+        assert a.ctx is party_ctx and a.to_ints() == ea.to_ints() and b.to_ints() == eb.to_ints()
+        for v in (a, b, ea, eb):
+            v.free()
+    party_ctx.close()
+
+
 def test_rep3_scatter_orders_against_the_party_stream(cozk, ctx):
     """the scatter's outputs are blocks of the PARTY's allocator but are written from the dealer's stream.  A block
     the party freed a moment ago may still be read by a kernel in flight on the party's stream: the scatter must not

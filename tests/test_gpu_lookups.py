@@ -130,7 +130,7 @@ def test_2p14_54_memories_verifies_and_rep3_equals_plain(cozk):
 @pytest.mark.parametrize("mode", ["plain", "rep3"])
 @pytest.mark.parametrize("cfg", [dict(log_n=1, n_pairs=3, density_pct=50, seed=4), dict(log_n=3, n_pairs=19, density_pct=30, seed=4),
                                  dict(log_n=4, n_pairs=8, density_pct=30, seed=11), dict(log_n=5, n_pairs=21, density_pct=20, seed=12),
-                                 dict(log_n=7, n_pairs=54, density_pct=30, seed=6)])
+                                 dict(log_n=7, n_pairs=54, density_pct=30, seed=6), dict(log_n=6, n_pairs=54, density_pct=10, seed=9, mix="sha2")])
 def test_primary_sumcheck_proofs_bit_identical_to_the_oracle(cozk, mode, cfg):
     """Lasso's primary sumcheck (SURVEY 8(f)1b) + the toggled grand product in one proof: the 27 RV32I instructions' collation
     forms (13 of them), degree-8 round polynomials (8 evaluations per round), up to three mul_vec / reshare levels per round in
@@ -140,7 +140,7 @@ def test_primary_sumcheck_proofs_bit_identical_to_the_oracle(cozk, mode, cfg):
     h = LK.LookupsHarness(mode=mode, primary=True, **cfg)
     res = h.prove(verify=True)
     assert res.verified == 1, h.last_error()
-    ref = pylookups.run(dict(cfg, mode=mode, primary=1))
+    ref = pylookups.run(dict(cfg, mode=mode, primary=1, mix=1 if cfg.get("mix") == "sha2" else 0))
     assert ref["verified"]
     assert h.proof_bytes(res) == ref["proof_bytes"]
     if mode == "rep3" and cfg["log_n"] >= 3:

@@ -12,12 +12,13 @@ ap.add_argument("--pairs", type=int, default=54)
 ap.add_argument("--density", type=int, default=10)
 ap.add_argument("--steps", type=int, default=3)
 ap.add_argument("--primary", action="store_true", help="also run Lasso's primary sumcheck (8f1b)")
+ap.add_argument("--mix", choices=["uniform", "sha2"], default="uniform", help="instruction mix of the synthetic trace (sha2: trace-shaped, ~6 %% multiplicative)")
 args = ap.parse_args()
 LK = importlib.import_module("co-zkvms_amd.lookups")
 ngpu = torch.cuda.device_count()
 devs = (0, 1, 2) if ngpu >= 3 else (0, 0, 0)
 t0 = time.time()
-h = LK.LookupsHarness(mode=args.mode, log_n=args.log_n, n_pairs=args.pairs, density_pct=args.density, seed=2026, devices=devs, primary=args.primary)
+h = LK.LookupsHarness(mode=args.mode, log_n=args.log_n, n_pairs=args.pairs, density_pct=args.density, seed=2026, devices=devs, primary=args.primary, mix=args.mix)
 setup_s = time.time() - t0
 r = h.prove(verify=True)
 assert r.verified == 1, h.last_error()
@@ -25,7 +26,7 @@ t0 = time.perf_counter()
 for _ in range(args.steps):
     r = h.prove(verify=False)
 dt = (time.perf_counter() - t0) / args.steps
-print(json.dumps({"what": ("Lasso primary sumcheck + " if args.primary else "") + "toggled grand product (instruction lookups read/write memory checking)", "mode": args.mode, "log_n": args.log_n,
+print(json.dumps({"what": ("Lasso primary sumcheck + " if args.primary else "") + "toggled grand product (instruction lookups read/write memory checking)", "mode": args.mode, "mix": args.mix, "log_n": args.log_n,
                   "memories": args.pairs, "circuits": 2 * args.pairs, "density_pct": args.density, "devices": list(devs), "verified": 1,
                   "ms_per_proof": round(dt * 1e3, 2), "cycles_per_s": round((1 << args.log_n) / dt, 1),
                   "phases_ms": {"primary_sumcheck": round(r.t_primary_ms, 2), "gp_construct": round(r.t_construct_ms, 2), "gp_prove": round(r.t_prove_ms, 2)},
