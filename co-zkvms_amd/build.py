@@ -7,7 +7,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OUT = os.path.join(HERE, "libcozk.so")
 SOURCES = ["capi.hip", "msm.hip", "poly.hip", "harness.hip", "shm_hub.hip", "ring.hip"]
-HEADERS = ["fr9.hip.hpp", "fr9_consts.inc", os.path.join("host", "flow_harness.hpp"), os.path.join("host", "jolt_r1cs.hpp"), os.path.join("host", "spartan_jolt.hpp"), "spartan_inner.inc", "ff.hip.hpp", "prf.hip.hpp", "ff_macc.inc", "ff_mul2.inc", "ec.hip.hpp", "fq9.hip.hpp", "fq9_consts.inc", "fq9_mac.inc", "fq9_mul.inc", "common.hpp", "poly.hip.hpp", "toggle_layer.inc", "primary_sumcheck.inc", "spartan_outer.inc", "logup.inc", os.path.join("host", "wire.hpp"), os.path.join("host", "net.hpp"), os.path.join("host", "prover.hpp"), os.path.join("host", "split.hpp"), os.path.join("host", "split_harness.hpp"), os.path.join("host", "spartan_harness.hpp"), os.path.join("host", "lookups_harness.hpp"), os.path.join("host", "outer_harness.hpp"), os.path.join("..", "..", "include", "cozk.h")]
+HEADERS = [os.path.join("host", "spartan_pub_workers.hpp"), "fr9.hip.hpp", "fr9_consts.inc", os.path.join("host", "flow_harness.hpp"), os.path.join("host", "jolt_r1cs.hpp"), os.path.join("host", "spartan_jolt.hpp"), "spartan_inner.inc", "ff.hip.hpp", "prf.hip.hpp", "ff_macc.inc", "ff_mul2.inc", "ec.hip.hpp", "fq9.hip.hpp", "fq9_consts.inc", "fq9_mac.inc", "fq9_mul.inc", "common.hpp", "poly.hip.hpp", "toggle_layer.inc", "primary_sumcheck.inc", "spartan_outer.inc", "logup.inc", os.path.join("host", "wire.hpp"), os.path.join("host", "net.hpp"), os.path.join("host", "prover.hpp"), os.path.join("host", "split.hpp"), os.path.join("host", "split_harness.hpp"), os.path.join("host", "spartan_harness.hpp"), os.path.join("host", "lookups_harness.hpp"), os.path.join("host", "outer_harness.hpp"), os.path.join("..", "..", "include", "cozk.h")]
 
 
 def _newer(target, deps):

@@ -45,6 +45,18 @@ struct SpartanParty {
     std::string error;
 };
 
+// cfg.log_pub_workers > 0: public worker j of 2^k with chunk j of the index (setup.rs split_ipk); own context and stream on
+// party 0's device, reading party 0's resident index through chunk views
+struct SpartanPubWorker {
+    cozk_ctx* ctx = nullptr;
+    int id = 0;
+    std::unique_ptr<PST13Setup> setup_slice;  // split_ck: ck_index over the low qv - k variables, generator g^{eq(t_high, j)}
+    VecH rows_pad, cols_pad;                  // rows / cols of the chunk, the padding spelled out with the first term (q_row, q_col)
+    double t_lookup = 0;
+    uint64_t star_up = 0, star_down = 0, star_msgs = 0;
+    std::string error;
+};
+
 struct SpartanProof {
     PST13Commitment cz;
     std::vector<std::vector<fe>> sc1;  // nv x 4 evaluations at X = 0..3
@@ -94,6 +106,7 @@ struct cozk_spartan {
     int nparties = 1;
     size_t n = 0;
     std::vector<SpartanParty> parties;
+    std::vector<SpartanPubWorker> pub;  // cfg.log_pub_workers > 0
     // host copy of the instance for the verifier (entry e = 3 row + k)
     std::vector<uint32_t> h_col;
     std::vector<fe> h_va, h_vb, h_vc;
@@ -269,6 +282,34 @@ static void spartan_setup_party(cozk_spartan* h, SpartanParty& ps, const std::ve
     }
 }
 
+// ListOfProductsOfPolynomials of the lookup sumcheck (worker.rs:469-541; append_sumcheck_polys, sumcheck.rs:459-500) over the
+// 15 polynomials eq_rx, eq_ry, val_m, then per lookup (base 3: rows, base 9: columns) lagrange, h_0, phi_0, m, h_1, phi_1
+struct LookupProducts {
+    std::vector<fe> coefs;
+    std::vector<int> counts, factors;
+    void add(const fe& cf, std::initializer_list<int> idx) {
+        coefs.push_back(cf);
+        counts.push_back((int)idx.size());
+        for (int i : idx) factors.push_back(i);
+    }
+    void append(int b, const fe& lam) {
+        fe eta = lam;
+        add(lam, {b + 1});
+        eta = Fr::mul(eta, lam);
+        add(eta, {b, b + 1, b + 2});
+        add(Fr::neg(eta), {b, b + 3});  // degree_diff = 0: 2^-0 = 1
+        add(Fr::neg(lam), {b + 4});
+        eta = Fr::mul(eta, lam);
+        add(eta, {b, b + 4, b + 5});
+        add(Fr::neg(eta), {b});
+    }
+    LookupProducts(const fe& lam_r, const fe& lam_c) {
+        add(Fr::one(), {0, 1, 2});
+        append(3, lam_r);
+        append(9, lam_c);
+    }
+};
+
 // --------------------------------------------------------------------------- public lookup round (cfg.lookup_round)
 // The schedule every participant follows (only party 0 computes; the others answer with empty messages, as the reference's
 // inactive workers answer with defaults, worker.rs:344-361):
@@ -389,30 +430,11 @@ static void spartan_lookup_worker(cozk_spartan* h, SpartanParty& ps, StarNetWork
         COZK_REQUIRE((int)z_r.size() == qv && (int)z_c.size() == qv, "spartan: lookup z length");
     }
     VecH lag_r = eq_le_device(ctx, z_r), lag_c = eq_le_device(ctx, z_c);  // partial_generate_eq over the whole domain
-    // ListOfProductsOfPolynomials (worker.rs:469-541; append_sumcheck_polys, sumcheck.rs:459-500)
     const cozk_vec* polys[15] = {erx.h,   ery.h,   val_m_vec.h, lag_r.h, lr[0].h, lr[1].h, ps.freq_r.h, lr[2].h,
                                  lr[3].h, lag_c.h, lc[0].h,     lc[1].h, ps.freq_c.h, lc[2].h, lc[3].h};
-    std::vector<fe> coefs;
-    std::vector<int> counts, factors;
-    auto add_product = [&](const fe& cf, std::initializer_list<int> idx) {
-        coefs.push_back(cf);
-        counts.push_back((int)idx.size());
-        for (int i : idx) factors.push_back(i);
-    };
-    add_product(Fr::one(), {0, 1, 2});
-    auto append = [&](int b, const fe& lam) {
-        fe eta = lam;
-        add_product(lam, {b + 1});
-        eta = Fr::mul(eta, lam);
-        add_product(eta, {b, b + 1, b + 2});
-        add_product(Fr::neg(eta), {b, b + 3});  // degree_diff = 0: 2^-0 = 1
-        add_product(Fr::neg(lam), {b + 4});
-        eta = Fr::mul(eta, lam);
-        add_product(eta, {b, b + 4, b + 5});
-        add_product(Fr::neg(eta), {b});
-    };
-    append(3, lam_r);
-    append(9, lam_c);
+    LookupProducts lp(lam_r, lam_c);
+    const std::vector<fe>& coefs = lp.coefs;
+    const std::vector<int>&counts = lp.counts, &factors = lp.factors;
     std::vector<uint64_t> cabi = to_abi(coefs);
     cozk_prodlist* pl = nullptr;
     rc_check(cozk_prodlist_create(ctx, polys, 15, cabi.data(), counts.data(), factors.data(), coefs.size(), &pl), ctx, "prodlist_create");
@@ -478,6 +500,10 @@ static void spartan_lookup_worker(cozk_spartan* h, SpartanParty& ps, StarNetWork
         star->send_response(w.b);
     }
 }
+
+}  // namespace
+#include "spartan_pub_workers.hpp"
+namespace {
 
 // --------------------------------------------------------------------------- worker
 static void spartan_worker_main(cozk_spartan* h, SpartanParty& ps, StarNetWorker* star) {
@@ -582,7 +608,7 @@ static void spartan_worker_main(cozk_spartan* h, SpartanParty& ps, StarNetWorker
     }
     double t6 = now_ms();
     ps.t_open = t6 - t5;
-    if (c.lookup_round) {
+    if (c.lookup_round && c.log_pub_workers == 0) {
         spartan_lookup_worker(h, ps, star, rx, ry, coef);
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         ps.t_lookup = now_ms() - t6;
@@ -783,7 +809,8 @@ static bool spartan_verify(cozk_spartan* h, const SpartanProof& pf, std::string&
     return true;
 }
 
-static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, SpartanProof& pf, bool verify, std::string& why) {
+static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, StarNetCoordinator* pnet, SpartanProof& pf, bool verify,
+                                    std::string& why) {
     const cozk_spartan_config& c = h->cfg;
     int nv = c.log_n;
     Transcript tr("cozk-spartan");
@@ -818,6 +845,7 @@ static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, Sp
             }
         }
     };
+    std::vector<fe> rx, ry;
     // first sumcheck: 4 additive evaluations per party per round
     for (int j = 0; j < nv; j++) {
         std::vector<fe> ev(4, Fr::zero());
@@ -829,6 +857,7 @@ static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, Sp
         }
         tr.append_scalars(ev);
         fe r = tr.challenge_scalar();
+        rx.push_back(r);
         pf.sc1.push_back(ev);
         Writer w;
         w.fr(r);
@@ -855,6 +884,7 @@ static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, Sp
         }
         tr.append_scalars(ev);
         fe r = tr.challenge_scalar();
+        ry.push_back(r);
         pf.sc2.push_back(ev);
         Writer w;
         w.fr(r);
@@ -867,7 +897,10 @@ static int spartan_coordinator_main(cozk_spartan* h, StarNetCoordinator& net, Sp
         pf.z_eval = Fr::add(pf.z_eval, rd.fr());
     }
     pf.opening = PST13::coordinate_prove(net);
-    if (c.lookup_round) {
+    if (c.lookup_round && c.log_pub_workers > 0) {
+        COZK_REQUIRE(pnet, "spartan: the public workers' star is missing");
+        spartan_coordinate_lookup_split(h, *pnet, tr, pf, rx, ry, abc);
+    } else if (c.lookup_round) {
         // fourth_round, coordinator side (coordinator.rs:475-591) after third_round's public claims (:430-470)
         const int qv = h->qv;
         {
@@ -951,6 +984,8 @@ int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out) {
     try {
         COZK_REQUIRE(cfg->mode == COZK_MODE_PLAIN || cfg->mode == COZK_MODE_REP3, "spartan: bad mode");
         COZK_REQUIRE(cfg->log_n >= 2 && cfg->log_n <= 24, "spartan: log_n out of range");
+        COZK_REQUIRE(cfg->log_pub_workers >= 0 && cfg->log_pub_workers <= 3, "spartan: log_pub_workers out of range (0..3)");
+        COZK_REQUIRE(cfg->log_pub_workers == 0 || cfg->lookup_round, "spartan: log_pub_workers needs lookup_round");
         h->nparties = cfg->mode == COZK_MODE_REP3 ? 3 : 1;
         h->n = (size_t)1 << cfg->log_n;
         h->qv = cfg->log_n + 2;  // 3 n entries padded to 4 n (indexer.rs:176-178)
@@ -965,6 +1000,19 @@ int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out) {
             ps.own_ctx = true;
             HIP_TRY(hipSetDevice(ps.ctx->device));
             spartan_setup_party(h, ps, z_plain);
+        }
+        if (cfg->log_pub_workers > 0) {
+            int K = 1 << cfg->log_pub_workers;
+            h->pub.resize((size_t)K);
+            for (int j = 0; j < K; j++) {
+                SpartanPubWorker& pw = h->pub[(size_t)j];
+                pw.id = j;
+                // party 0's device: the workers read its resident index in place
+                int rc = cozk_ctx_create(cfg->devices[0], &pw.ctx);
+                if (rc != COZK_OK) throw CozkError(rc, "spartan: cannot create a public worker's context");
+                HIP_TRY(hipSetDevice(pw.ctx->device));
+                spartan_setup_pub_worker(h, pw);
+            }
         }
     } catch (const CozkError& e) {
         h->error = e.what();
@@ -983,6 +1031,13 @@ const char* cozk_spartan_error(const cozk_spartan* h) { return h ? h->error.c_st
 
 int cozk_spartan_destroy(cozk_spartan* h) {
     if (!h) return COZK_OK;
+    for (auto& pw : h->pub) {
+        if (pw.ctx) (void)hipSetDevice(pw.ctx->device);
+        pw.rows_pad = VecH();
+        pw.cols_pad = VecH();
+        pw.setup_slice.reset();
+        if (pw.ctx) cozk_ctx_destroy(pw.ctx);
+    }
     for (auto& ps : h->parties) {
         if (ps.ctx) (void)hipSetDevice(ps.ctx->device);
         ps.z = PolyH();
@@ -1008,6 +1063,16 @@ int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res) {
         sw.emplace_back(new InProcStarWorker(&star, p));
         h->parties[p].error.clear();
     }
+    // the public workers' own star (log_pub_workers > 0); one abort flag for both
+    const int K = (int)h->pub.size();
+    InProcStar pstar(K > 0 ? K : 1);
+    for (auto& ch : pstar.up) ch.abort = &star.abort;
+    for (auto& ch : pstar.down) ch.abort = &star.abort;
+    std::vector<std::unique_ptr<InProcStarWorker>> psw;
+    for (int j = 0; j < K; j++) {
+        psw.emplace_back(new InProcStarWorker(&pstar, j));
+        h->pub[(size_t)j].error.clear();
+    }
     std::vector<std::thread> threads;
     double t0 = now_ms();
     for (int p = 0; p < np; p++) {
@@ -1020,14 +1085,24 @@ int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res) {
             }
         });
     }
+    for (int j = 0; j < K; j++) {
+        threads.emplace_back([&, j] {
+            try {
+                spartan_pub_worker_main(h, h->pub[(size_t)j], psw[(size_t)j].get());
+            } catch (const std::exception& e) {
+                h->pub[(size_t)j].error = e.what();
+                star.abort.flag.store(true);
+            }
+        });
+    }
     SpartanProof proof;
     std::string why;
     int verified = -1;
     int rc = COZK_OK;
     double t_prove_end = 0;
     try {
-        InProcStarCoordinator coord(&star);
-        verified = spartan_coordinator_main(h, coord, proof, verify != 0, why);
+        InProcStarCoordinator coord(&star), pcoord(&pstar);
+        verified = spartan_coordinator_main(h, coord, K > 0 ? &pcoord : nullptr, proof, verify != 0, why);
     } catch (const std::exception& e) {
         h->error = std::string("coordinator: ") + e.what();
         star.abort.flag.store(true);
@@ -1041,10 +1116,23 @@ int cozk_spartan_prove(cozk_spartan* h, int verify, cozk_spartan_result* res) {
             rc = COZK_ERR_INTERNAL;
         }
     }
+    for (int j = 0; j < K; j++) {
+        if (!h->pub[(size_t)j].error.empty()) {
+            h->error = "public worker " + std::to_string(j) + ": " + h->pub[(size_t)j].error;
+            rc = COZK_ERR_INTERNAL;
+        }
+    }
     if (rc != COZK_OK) return rc;
     if (verified == 0) h->error = "verification failed: " + why;
     res->verified = verified;
     res->wall_ms = t_prove_end - t0;
+    res->pub_workers = K > 0 ? K : (h->cfg.lookup_round ? 1 : 0);
+    for (auto& pw : h->pub) {
+        res->t_lookup_ms = std::max(res->t_lookup_ms, pw.t_lookup);
+        res->pub_star_messages += pw.star_msgs;
+        res->pub_bytes_up += pw.star_up;
+        res->pub_bytes_down += pw.star_down;
+    }
     for (int p = 0; p < np; p++) {
         SpartanParty& ps = h->parties[p];
         res->t_zero_round_ms = std::max(res->t_zero_round_ms, ps.t_zero);

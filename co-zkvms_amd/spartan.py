@@ -8,7 +8,7 @@ from . import _lib as L
 
 class SpartanConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("precompute", ctypes.c_int), ("devices", ctypes.c_int * 3),
-                ("seed", ctypes.c_uint64), ("lookup_round", ctypes.c_int)]
+                ("seed", ctypes.c_uint64), ("lookup_round", ctypes.c_int), ("log_pub_workers", ctypes.c_int)]
 
 
 class SpartanResult(ctypes.Structure):
@@ -16,7 +16,9 @@ class SpartanResult(ctypes.Structure):
                 ("t_commit_ms", ctypes.c_double), ("t_sumcheck1_ms", ctypes.c_double), ("t_matrix_build_ms", ctypes.c_double),
                 ("t_sumcheck2_ms", ctypes.c_double), ("t_open_ms", ctypes.c_double), ("t_worker_ms", ctypes.c_double),
                 ("bytes_star_up", ctypes.c_uint64), ("bytes_star_down", ctypes.c_uint64), ("star_messages", ctypes.c_uint64),
-                ("proof_len", ctypes.c_uint64), ("proof_digest", ctypes.c_uint8 * 32), ("t_lookup_ms", ctypes.c_double)]
+                ("proof_len", ctypes.c_uint64), ("proof_digest", ctypes.c_uint8 * 32), ("t_lookup_ms", ctypes.c_double),
+                ("pub_workers", ctypes.c_int), ("pub_star_messages", ctypes.c_uint64), ("pub_bytes_up", ctypes.c_uint64),
+                ("pub_bytes_down", ctypes.c_uint64)]
 
 
 SPARTAN_SYMBOLS = ["cozk_spartan_create", "cozk_spartan_error", "cozk_spartan_destroy", "cozk_spartan_prove", "cozk_spartan_proof_bytes"]
@@ -38,7 +40,7 @@ def _decl():
 
 
 class SpartanHarness:
-    def __init__(self, mode="plain", log_n=10, precompute=True, devices=(0, 0, 0), seed=1, lookup_round=False):
+    def __init__(self, mode="plain", log_n=10, precompute=True, devices=(0, 0, 0), seed=1, lookup_round=False, log_pub_workers=0):
         self._l = _decl()
         cfg = SpartanConfig()
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
@@ -47,6 +49,7 @@ class SpartanHarness:
         cfg.devices = (ctypes.c_int * 3)(*devices)
         cfg.seed = seed
         cfg.lookup_round = 1 if lookup_round else 0
+        cfg.log_pub_workers = log_pub_workers
         h = ctypes.c_void_p()
         rc = self._l.cozk_spartan_create(ctypes.byref(cfg), ctypes.byref(h))
         self.h = h

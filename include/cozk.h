@@ -333,7 +333,7 @@ int cozk_toggle_download(cozk_ctx* ctx, const cozk_toggle* t, uint64_t* flags, u
  *   sum_x eq(r, x) ( sum_i flag_i(x) g_i(E_1(x), .., E_alpha(x)) - lookup_output(x) ) = 0.
  * cozk_primary holds eq (public), the instruction flags (public 0/1 U8 columns), the E polynomials and lookup_outputs
  * (shared) and binds them LowToHigh once per round.  The collations g_i (combine_lookups_rep3_batched,
- * co-jolt/src/jolt/instruction/*.rs) are given as a table of forms over memory indices:
+ * co-jolt/src/jolt/instruction/, one .rs each) are given as a table of forms over memory indices:
  *   COZK_G_CONCAT  (and.rs:89-101, utils/instruction_utils.rs:26-47): sum_j 2^(bits (n-1-j)) E_mems[j]        -- local
  *                  ADD SUB AND OR XOR SLL MUL MULU MULHU VIRTUAL_ADVICE VIRTUAL_MOVE; bits = 0: the plain sum of SRA / SRL
  *                  (sra.rs:122-132); the same memory listed twice: MOVSIGN (virtual_movsign.rs:126-139)
@@ -667,6 +667,12 @@ typedef struct cozk_spartan_config {
                        * third_round's tail (worker.rs:296-343: val_a, val_b, val_c, commitments of eq_tilde_rx / ry) and
                        * fourth_round (worker.rs:398-575: two logup lookups, distributed sumcheck, batch opening of 15
                        * polynomials under ck_index); its proof part is appended and verified (spartan/src/logup.rs:117-190) */
+    int log_pub_workers; /* 0..3 (needs lookup_round): 2^k public workers, each on chunk j of the index as setup.rs's split_ipk
+                          * deals it (rows / cols / val / freq chunks, the SRS slice of ck_index with its generator scaled by
+                          * eq(t_high, j)); the coordinator sums val_a, val_b, val_c and the commitments (coordinator.rs:425-475),
+                          * sums the sumcheck messages of the first qv - k rounds, proves the last k rounds itself on the
+                          * gathered finals (distributed_sumcheck_coordinator, coordinator.rs:748-811), and finishes the batched
+                          * opening's last k folds.  The proof bytes equal the one-worker proof. */
 } cozk_spartan_config;
 typedef struct cozk_spartan_result {
     int verified; /* 1 ok, 0 rejected, -1 not run */
@@ -676,6 +682,8 @@ typedef struct cozk_spartan_result {
     uint64_t proof_len;
     uint8_t proof_digest[32]; /* SHA-256 of the serialized proof */
     double t_lookup_ms;       /* cfg.lookup_round: the public worker's third-round tail + fourth round */
+    int pub_workers;          /* public workers that proved the lookup round (1 << log_pub_workers) */
+    uint64_t pub_star_messages, pub_bytes_up, pub_bytes_down; /* their star (log_pub_workers > 0) */
 } cozk_spartan_result;
 int cozk_spartan_create(const cozk_spartan_config* cfg, cozk_spartan** out);
 const char* cozk_spartan_error(const cozk_spartan* h);

@@ -86,3 +86,39 @@ def test_lookup_round_2p14_verifies_and_rep3_equals_plain(cozk):
         digs.append(_digest(r1))
         h.close()
     assert digs[0] == digs[1]
+
+
+@pytest.mark.parametrize("mode", ["plain", "rep3"])
+@pytest.mark.parametrize("log_n,seed,ks", [(2, 3, (1, 2, 3)), (3, 5, (1, 2)), (5, 7, (1, 2, 3))])
+def test_lookup_round_over_public_workers_gives_the_one_worker_proof(cozk, mode, log_n, seed, ks):
+    """co-noir-spartan/co-spartan/src/setup.rs split_ipk / split_ck + coordinator.rs:425-475,748-811: 2, 4 and 8 public workers
+    each prove their chunk of the index (rows / cols / val / multiplicities, the SRS slice scaled by eq(t_high, j)); the
+    coordinator sums val_a/b/c, the commitments and the first qv - k sumcheck rounds, proves the last k rounds on the gathered
+    prover states and finishes the batched opening.  The proof must be the one-worker proof byte for byte (= the oracle's)."""
+    ref = pyspartan.run(dict(log_n=log_n, seed=seed, lookup_round=1))
+    assert ref["verified"]
+    for k in ks:
+        h = cozk.SpartanHarness(mode=mode, log_n=log_n, seed=seed, lookup_round=True, log_pub_workers=k)
+        res = h.prove(verify=True)
+        assert res.verified == 1, h.last_error()
+        assert res.pub_workers == 1 << k and res.pub_star_messages > 0
+        assert h.proof_bytes(res) == ref["proof_bytes"], f"k = {k}"
+        h.close()
+
+
+def test_lookup_round_public_workers_2p14_digest_equals_one_worker(cozk):
+    h = cozk.SpartanHarness(mode="plain", log_n=14, seed=2026, lookup_round=True)
+    want = _digest(h.prove(verify=True))
+    h.close()
+    for mode, k in (("plain", 1), ("plain", 2), ("rep3", 2)):
+        h = cozk.SpartanHarness(mode=mode, log_n=14, seed=2026, lookup_round=True, log_pub_workers=k)
+        r = h.prove(verify=True)
+        assert r.verified == 1, h.last_error()
+        assert _digest(r) == want
+        assert _digest(h.prove(verify=False)) == want  # repeatable on the same harness
+        h.close()
+
+
+def test_public_workers_need_the_lookup_round(cozk):
+    with pytest.raises(cozk.CozkError):
+        cozk.SpartanHarness(mode="plain", log_n=4, seed=1, lookup_round=False, log_pub_workers=1)
