@@ -9,6 +9,8 @@
 // one-block kernel, and returned through pinned host memory.
 #include <atomic>
 #include <chrono>
+#include <map>
+#include <mutex>
 #include <string.h>
 #include "poly.hip.hpp"
 #include "prf.hip.hpp"
@@ -50,6 +52,32 @@ static inline unsigned grid_for(size_t n) { return (unsigned)((n + PT - 1) / PT)
 static inline unsigned grid_capped(size_t n) {
     size_t g = (n + PT - 1) / PT;
     return (unsigned)(g > MAXBLK ? MAXBLK : (g ? g : 1));
+}
+
+// Grid of a grid-stride kernel whose waves are long (thousands of instructions per element): exactly the workgroups the chip
+// holds at once (occupancy query x CUs), so that every wave is resident from the start and the last residency round is not a
+// partial one.  Measured on the 2^24-element probe with the LDS-staged 9 x 29 kernels (compute-bound): 0.311 vs 0.334 ms plain,
+// 0.486 vs 0.505 ms Rep3 against the former fixed cap of 1024 workgroups (COZK_RESIDENT_GRID=0 restores it for A/B runs).
+static unsigned resident_grid(const void* kernel, size_t nblocks_needed, int device) {
+    static const int legacy = getenv("COZK_RESIDENT_GRID") && atoi(getenv("COZK_RESIDENT_GRID")) == 0;  // A/B switch: the old cap
+    if (legacy) return (unsigned)(nblocks_needed < 1024 ? (nblocks_needed ? nblocks_needed : 1) : 1024);
+    static std::mutex mu;
+    static std::map<std::pair<const void*, int>, unsigned> cache;
+    unsigned cap;
+    {
+        std::lock_guard<std::mutex> g(mu);
+        auto it = cache.find({kernel, device});
+        if (it == cache.end()) {
+            int per_cu = 0, cus = 0;
+            HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, PT, 0));
+            HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+            unsigned v = (unsigned)(per_cu > 0 ? per_cu : 1) * (unsigned)(cus > 0 ? cus : 1);
+            if (v > MAXBLK) v = MAXBLK;
+            it = cache.emplace(std::make_pair(kernel, device), v).first;
+        }
+        cap = it->second;
+    }
+    return (unsigned)(nblocks_needed < cap ? (nblocks_needed ? nblocks_needed : 1) : cap);
 }
 
 static const fe* poly_a(const cozk_poly* p) { return p->cur < 0 ? p->a0 : p->buf[p->cur][0]; }
@@ -485,19 +513,83 @@ static __device__ __forceinline__ void layer9_finish(const f9& s0, const f9& s2,
     if (threadIdx.x == 0) fe_store(partial + 2 * gridDim.x + blockIdx.x, v);
 }
 
+
+// ---- wave-private LDS staging of layer data (round 3).  A lane owns 128 consecutive bytes (4 field elements) of a row; read or
+// written straight from the lane, a wave's dwordx4 instruction touches 64 different 128-byte lines 16 bytes at a time and every line
+// is re-referenced by eight instructions (nontemporal accesses, which forbid that re-use, slowed the unstaged round 1.5-2 x).  Staged,
+// instruction k moves rows 8k .. 8k+7 as eight WHOLE lines (lane l: row 8k + l / 8, 16-byte piece l % 8) and the lanes trade pieces
+// through a wave-private LDS window of 64 rows x 144 bytes (128 + 16: a b128 access of 16 lanes then covers 16 distinct bank quads).
+// A wave's LDS instructions execute in order; the fences keep the compiler from reordering them across the exchange.
+static constexpr int ST_ROW = 144;
+static constexpr int ST_WAVE_BYTES = 64 * ST_ROW;
+static __device__ __forceinline__ void stage_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// out[0..3] <- the 4 elements at g + lane * row_stride (bytes); the wave's 64 rows are all in range
+static __device__ __forceinline__ void stage_in_rows(const char* __restrict__ g, size_t row_stride, char* st, fe out[4]) {
+    const int lane = threadIdx.x & 63, piece = lane & 7, sub = lane >> 3;
+    uint4 t[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) t[k] = *reinterpret_cast<const uint4*>(g + (size_t)(8 * k + sub) * row_stride + 16 * piece);
+#pragma unroll
+    for (int k = 0; k < 8; k++) *reinterpret_cast<uint4*>(st + (8 * k + sub) * ST_ROW + 16 * piece) = t[k];
+    stage_fence();
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const uint4 lo = *reinterpret_cast<const uint4*>(st + lane * ST_ROW + 32 * j);
+        const uint4 hi = *reinterpret_cast<const uint4*>(st + lane * ST_ROW + 32 * j + 16);
+        out[j].l[0] = lo.x; out[j].l[1] = lo.y; out[j].l[2] = lo.z; out[j].l[3] = lo.w;
+        out[j].l[4] = hi.x; out[j].l[5] = hi.y; out[j].l[6] = hi.z; out[j].l[7] = hi.w;
+    }
+    stage_fence();  // the window is free again once every lane has its row
+}
+// the 4 elements of this lane -> g + lane * 128 (rows of a wave are contiguous on the way out)
+static __device__ __forceinline__ void stage_out_rows(char* __restrict__ g, char* st, const fe in[4]) {
+    const int lane = threadIdx.x & 63, piece = lane & 7, sub = lane >> 3;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        *reinterpret_cast<uint4*>(st + lane * ST_ROW + 32 * j) = make_uint4(in[j].l[0], in[j].l[1], in[j].l[2], in[j].l[3]);
+        *reinterpret_cast<uint4*>(st + lane * ST_ROW + 32 * j + 16) = make_uint4(in[j].l[4], in[j].l[5], in[j].l[6], in[j].l[7]);
+    }
+    stage_fence();
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+        *reinterpret_cast<uint4*>(g + (size_t)(8 * k + sub) * 128 + 16 * piece) = *reinterpret_cast<const uint4*>(st + (8 * k + sub) * ST_ROW + 16 * piece);
+    stage_fence();
+}
+
 template <int NC, int NESTED>
 __global__ void __launch_bounds__(PT) k_layer_cubic9(const fe* __restrict__ a, const fe* __restrict__ b, size_t len, const fe* __restrict__ E1, size_t E1_half,
                                                   const fe* __restrict__ E2, size_t E2_len, fe* __restrict__ partial) {
     __shared__ fe sh4[4];
+    __shared__ __attribute__((aligned(16))) char stage[PT / 64][ST_WAVE_BYTES];
+    char* st = stage[threadIdx.x >> 6];
     size_t nch = (len + 3) / 4;
     const size_t limit = NESTED ? E1_half * E2_len : E2_len / 2;
     if (nch > limit) nch = limit;  // zip() stops at the shorter side
     const int e1_shift = NESTED ? __ffsll((long long)E1_half) - 1 : 0;
     f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
-    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch; c += (size_t)gridDim.x * PT) {
-        const Sh9<NC> l0 = sh9_load_or_zero<NC>(a, b, 4 * c, len), r0 = sh9_load_or_zero<NC>(a, b, 4 * c + 1, len);
-        const Sh9<NC> l1 = sh9_load_or_zero<NC>(a, b, 4 * c + 2, len), r1 = sh9_load_or_zero<NC>(a, b, 4 * c + 3, len);
-        layer9_terms<NC, NESTED>(l0, r0, l1, r1, E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+    // the trip count is per WAVE (c0 = the wave's first chunk): a wave whose 64 chunks are all inside the layer takes the staged path
+    for (size_t c0 = (size_t)blockIdx.x * PT + (threadIdx.x & ~63u); c0 < nch; c0 += (size_t)gridDim.x * PT) {
+        const size_t c = c0 + (threadIdx.x & 63);
+        if (c0 + 64 <= nch && 4 * (c0 + 64) <= len) {
+            Sh9<NC> q[4];
+            const fe* comp[2] = {a, b};
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                fe raw[4];
+                stage_in_rows(reinterpret_cast<const char*>(comp[k] + 4 * c0), 128, st, raw);
+#pragma unroll
+                for (int j = 0; j < 4; j++) q[j].c[k] = f9_from_fe(raw[j]);
+            }
+            layer9_terms<NC, NESTED>(q[0], q[1], q[2], q[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+        } else if (c < nch) {
+            const Sh9<NC> l0 = sh9_load_or_zero<NC>(a, b, 4 * c, len), r0 = sh9_load_or_zero<NC>(a, b, 4 * c + 1, len);
+            const Sh9<NC> l1 = sh9_load_or_zero<NC>(a, b, 4 * c + 2, len), r1 = sh9_load_or_zero<NC>(a, b, 4 * c + 3, len);
+            layer9_terms<NC, NESTED>(l0, r0, l1, r1, E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+        }
     }
     layer9_finish<NESTED>(s0, s2, s3, partial, sh4);
 }
@@ -514,8 +606,40 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic9(const fe* __restrict__
     const int e1_shift = NESTED ? __ffsll((long long)E1_half) - 1 : 0;
     const f9 r9 = f9_from_fe(r5);
     f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
-    for (size_t c = (size_t)blockIdx.x * PT + threadIdx.x; c < nch_out; c += (size_t)gridDim.x * PT) {
+    __shared__ __attribute__((aligned(16))) char stage[PT / 64][ST_WAVE_BYTES];
+    char* st = stage[threadIdx.x >> 6];
+    for (size_t c0 = (size_t)blockIdx.x * PT + (threadIdx.x & ~63u); c0 < nch_out; c0 += (size_t)gridDim.x * PT) {
+        const size_t c = c0 + (threadIdx.x & 63);
         Sh9<NC> v[4];
+        if (c0 + 64 <= nch_out && 8 * (c0 + 64) <= len_in) {
+            // staged: the wave's 64 x 8 inputs come in as whole lines (two halves of 4 elements per lane and component), its
+            // 64 x 4 outputs leave as whole lines
+            const fe* icomp[2] = {ia, ib};
+            fe* ocomp[2] = {oa, ob};
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                Sh9<NC> u[4];
+#pragma unroll
+                for (int k = 0; k < NC; k++) {
+                    fe raw[4];
+                    stage_in_rows(reinterpret_cast<const char*>(icomp[k] + 8 * c0 + 4 * h), 256, st, raw);
+#pragma unroll
+                    for (int j = 0; j < 4; j++) u[j].c[k] = f9_from_fe(raw[j]);
+                }
+                v[2 * h] = sh9_lerp<NC>(u[0], u[2], r9);
+                v[2 * h + 1] = sh9_lerp<NC>(u[1], u[3], r9);
+            }
+#pragma unroll
+            for (int k = 0; k < NC; k++) {
+                fe outv[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) outv[j] = fr9_to_canonical(v[j].c[k]);
+                stage_out_rows(reinterpret_cast<char*>(ocomp[k] + 4 * c0), st, outv);
+            }
+            if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+            continue;
+        }
+        if (c >= nch_out) continue;
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const size_t ci = 2 * c + h;
@@ -1969,7 +2093,7 @@ static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
     size_t nch = (l->len + 3) / 4;
     unsigned gx = grid_capped(nch);
     if (gx > 1024) gx = 1024;
-    ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
+    ctx->scratch.reserve((3 * (size_t)MAXBLK + 3) * sizeof(fe));
     fe* partial = ctx->scratch.as<fe>();
     fe* res = result_slot(ctx, 3);
     const fe* a = l->buf[l->cur][0];
@@ -1979,13 +2103,21 @@ static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
     bool nested = eq->E1_len != 1;
     static const int f9_env = getenv("COZK_LAYER_F9") ? atoi(getenv("COZK_LAYER_F9")) : 1;
     if (f9_env != 0 && (l->len + 3) / 4 >= 1024) {  // the 9 x 29 multiplier kernels (fr9.hip.hpp) for throughput-bound layers
+        const size_t need = (nch + PT - 1) / PT;
+        const int dev = ctx->device;
+#define COZK_CUBIC9(NC_, NE_, B_, E1H_)                                                                                             \
+    do {                                                                                                                            \
+        gx = resident_grid((const void*)k_layer_cubic9<NC_, NE_>, need, dev);                                                        \
+        k_layer_cubic9<NC_, NE_><<<gx, PT, 0, ctx->stream>>>(a, B_, l->len, E1, E1H_, E2, eq->E2_len, partial);                      \
+    } while (0)
         if (l->mode == COZK_MODE_REP3) {
-            if (nested) k_layer_cubic9<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
-            else k_layer_cubic9<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+            if (nested) COZK_CUBIC9(2, 1, b, eq->E1_len / 2);
+            else COZK_CUBIC9(2, 0, b, 0);
         } else {
-            if (nested) k_layer_cubic9<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
-            else k_layer_cubic9<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
+            if (nested) COZK_CUBIC9(1, 1, b, eq->E1_len / 2);
+            else COZK_CUBIC9(1, 0, b, 0);
         }
+#undef COZK_CUBIC9
     } else if (l->mode == COZK_MODE_REP3) {
         if (nested) k_layer_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
         else k_layer_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
@@ -2038,7 +2170,7 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
             size_t nch_out = (nout + 3) / 4;
             unsigned gx = grid_capped(nch_out);
             if (gx > 1024) gx = 1024;
-            ctx->scratch.reserve((3 * (size_t)gx + 3) * sizeof(fe));
+            ctx->scratch.reserve((3 * (size_t)MAXBLK + 3) * sizeof(fe));
             fe* partial = ctx->scratch.as<fe>();
             fe* res = result_slot(ctx, 3);
             fe rr = fe_from_u64x4(r);
@@ -2056,13 +2188,21 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
             if (f9_env != 0 && nch_out >= 1024) {
                 fe r5 = rr;
                 for (int d = 0; d < 5; d++) r5 = Fr::dbl(r5);  // the challenge times 2^5 = 1 / lambda (fr9.hip.hpp)
+                const size_t need = (nch_out + PT - 1) / PT;
+                const int dev = ctx->device;
+#define COZK_BIND_CUBIC9(NC_, NE_, IB_, OB_, E1H_)                                                                                  \
+    do {                                                                                                                            \
+        gx = resident_grid((const void*)k_layer_bind_cubic9<NC_, NE_>, need, dev);                                                   \
+        k_layer_bind_cubic9<NC_, NE_><<<gx, PT, 0, ctx->stream>>>(ia, IB_, oa, OB_, l->len, r5, E1, E1H_, E2, e->E2_len, partial);   \
+    } while (0)
                 if (l->mode == COZK_MODE_REP3) {
-                    if (nested) k_layer_bind_cubic9<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, r5, E1, e->E1_len / 2, E2, e->E2_len, partial);
-                    else k_layer_bind_cubic9<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, r5, E1, 0, E2, e->E2_len, partial);
+                    if (nested) COZK_BIND_CUBIC9(2, 1, ib, ob, e->E1_len / 2);
+                    else COZK_BIND_CUBIC9(2, 0, ib, ob, 0);
                 } else {
-                    if (nested) k_layer_bind_cubic9<1, 1><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, r5, E1, e->E1_len / 2, E2, e->E2_len, partial);
-                    else k_layer_bind_cubic9<1, 0><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, r5, E1, 0, E2, e->E2_len, partial);
+                    if (nested) COZK_BIND_CUBIC9(1, 1, nullptr, nullptr, e->E1_len / 2);
+                    else COZK_BIND_CUBIC9(1, 0, nullptr, nullptr, 0);
                 }
+#undef COZK_BIND_CUBIC9
             } else if (l->mode == COZK_MODE_REP3) {
                 if (nested) k_layer_bind_cubic<2, 1><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, e->E1_len / 2, E2, e->E2_len, partial);
                 else k_layer_bind_cubic<2, 0><<<gx, PT, 0, ctx->stream>>>(ia, ib, oa, ob, l->len, rr, E1, 0, E2, e->E2_len, partial);
