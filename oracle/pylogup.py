@@ -123,6 +123,39 @@ def distributed_sumcheck(polys, products, transcript):
     return msgs, point, [p[0] for p in polys]
 
 
+def distributed_sumcheck_split(polys, products, transcript, log_workers):
+    """distributed_sumcheck_worker x 2^k + distributed_sumcheck_coordinator (co-spartan/src/coordinator.rs:748-811): worker j holds
+    chunk j (the high k variables = j) of every polynomial, the coordinator sums the workers' messages of the first nv - k rounds and
+    proves the last k rounds itself on the workers' final states (obtain_distrbuted_sumcheck_prover_state, sumcheck.rs:434-452).
+    Returns (messages, point, final poly values) -- equal to distributed_sumcheck's by linearity of the round sums."""
+    degree = max(len(f) for _, f in products)
+    nv = len(polys[0]).bit_length() - 1
+    K = 1 << log_workers
+    cn = len(polys[0]) // K
+    assert cn >= 2
+    chunks = [[list(p[j * cn:(j + 1) * cn]) for p in polys] for j in range(K)]
+    msgs, point = [], []
+    for _ in range(nv - log_workers):
+        ev = [0] * (degree + 1)
+        for j in range(K):
+            part = prove_round(chunks[j], products, degree)
+            ev = [(a + b) % R for a, b in zip(ev, part)]
+        transcript.append_scalars(ev)
+        r = transcript.challenge_scalar()
+        msgs.append(ev)
+        point.append(r)
+        chunks = [fix_variables(c, r) for c in chunks]
+    merged = [[chunks[j][i][0] for j in range(K)] for i in range(len(polys))]  # polynomial i over the worker index
+    for _ in range(log_workers):
+        ev = prove_round(merged, products, degree)
+        transcript.append_scalars(ev)
+        r = transcript.challenge_scalar()
+        msgs.append(ev)
+        point.append(r)
+        merged = fix_variables(merged, r)
+    return msgs, point, [p[0] for p in merged]
+
+
 def verify_sumcheck(msgs, point, finals, products, claimed_sum):
     expected = claimed_sum % R
     for ev, r in zip(msgs, point):

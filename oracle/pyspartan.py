@@ -167,7 +167,7 @@ def run(cfg):
     blob += _ser_u64(len(sc2)) + b"".join(_ser_vec(e) for e in sc2) + _ser_vec(fin2)
     blob += _ser_fr(z_eval) + _ser_u64(len(proofs)) + b"".join(_ser_g1(p) for p in proofs)
     if cfg.get("lookup_round"):
-        lk_blob, lk_ok = lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr)
+        lk_blob, lk_ok = lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr, int(cfg.get("log_pub_workers", 0)))
         blob += lk_blob
         ok &= lk_ok
     return {"proof_bytes": blob, "digest": hashlib.sha256(blob).hexdigest(), "verified": bool(ok)}
@@ -194,9 +194,70 @@ def multiplicities(idx, size):
     return m
 
 
-def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
-    """third_round's public tail + fourth_round with one public worker; returns (proof bytes, verified)"""
+def index_ck_slice(ck, k, j):
+    """split_ck (co-spartan/src/setup.rs): public worker j's part of ck_index -- the key over the low qv - k variables whose generator
+    carries eq(t_high, j) (little-endian: bit b of j pairs with t[ql + b])"""
+    ql = ck["nv"] - k
+    t = ck["t"]
+    w = 1
+    for b in range(k):
+        w = w * (t[ql + b] if (j >> b) & 1 else (1 - t[ql + b])) % R
+    g = O.g1_mul(ck["g"], w)
+    powers = []
+    for i in range(ql):
+        ev = [1]
+        for tj in t[i:ql]:
+            ev = [e * (1 - tj) % R for e in ev] + [e * tj % R for e in ev]
+        powers.append([O.g1_mul(g, e) for e in ev])
+    return {"nv": ql, "t": t[:ql], "g": g, "powers_of_g": powers}
+
+
+def split_commit(ck, evals, k):
+    """coordinator.rs:425-475 as rep3_poly_commit_coordinator(.., Some(log_num_pub_workers)) sums it: the chunk commitments under the
+    workers' key slices add up to the commitment under ck_index"""
+    K = 1 << k
+    cn = len(evals) // K
+    acc = None
+    for j in range(K):
+        acc = O.g1_add(acc, O.pst_commit(index_ck_slice(ck, k, j), evals[j * cn:(j + 1) * cn]))
+    return acc
+
+
+def split_open(ck, evals, point, k):
+    """the batched opening over 2^k public workers: chunk-local quotient commitments add up; the last k quotients are committed by
+    the coordinator from the workers' folded values under g^{eq(t[level + 1 ..], b)} (= G_level[2b] + G_level[2b + 1])"""
+    K, qv = 1 << k, ck["nv"]
+    ql = qv - k
+    cn = len(evals) // K
+    proofs, folded = [None] * ql, []
+    for j in range(K):
+        pf, v = O.pst_open(index_ck_slice(ck, k, j), evals[j * cn:(j + 1) * cn], point[:ql])
+        proofs = [O.g1_add(a, b) for a, b in zip(proofs, pf)]
+        folded.append(v)
+    t = ck["t"]
+    for level in range(ql, qv):
+        m = qv - level
+        nxt, pi = [], None
+        for b in range(1 << (m - 1)):
+            q = (folded[2 * b + 1] - folded[2 * b]) % R
+            nxt.append((folded[2 * b] + q * point[level]) % R)
+            w = 1
+            for bit in range(m - 1):
+                w = w * (t[level + 1 + bit] if (b >> bit) & 1 else (1 - t[level + 1 + bit])) % R
+            pi = O.g1_add(pi, O.g1_mul(ck["g"], q * w % R))
+        folded = nxt
+        proofs.append(pi)
+    return proofs, folded[0]
+
+
+def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr, log_pub_workers=0):
+    """third_round's public tail + fourth_round; returns (proof bytes, verified).  log_pub_workers = k > 0 computes every merged
+    quantity the way 2^k public workers and the coordinator do (setup.rs split_ipk / split_ck, coordinator.rs:425-475,748-811): sums
+    of chunk claims, of chunk commitments under key slices, of chunk round messages, the coordinator's own last k rounds, the
+    opening finished from the folded values.  The bytes do not depend on k (tests/test_spartan_split_oracle.py)."""
     import pylogup as G
+    kpw = log_pub_workers
+    commit = (lambda ck_, v_: split_commit(ck_, v_, kpw)) if kpw else O.pst_commit
     n = 1 << nv
     real = len(entries)
     qv = max(1, (real - 1).bit_length())
@@ -211,8 +272,13 @@ def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
     # ---- third_round, public tail (worker.rs:296-343)
     erx = pad([eq_rx[r] for r in rows])  # eq_tilde_rx_chunk = eq_tilde_rx for the single public worker
     ery = pad([eq_ry[c] for c in cols])
-    val_abc = [sum(v[e] * erx[e] % R * ery[e] for e in range(real)) % R for v in (val_a, val_b, val_c)]
-    c_rx, c_ry = O.pst_commit(ck, erx), O.pst_commit(ck, ery)
+    if kpw:  # partial claims per chunk, summed by the coordinator
+        cn = NZ >> kpw
+        val_abc = [sum(sum(v[e] * erx[e] % R * ery[e] for e in range(j * cn, (j + 1) * cn)) % R for j in range(1 << kpw)) % R
+                   for v in (val_a, val_b, val_c)]
+    else:
+        val_abc = [sum(v[e] * erx[e] % R * ery[e] for e in range(real)) % R for v in (val_a, val_b, val_c)]
+    c_rx, c_ry = commit(ck, erx), commit(ck, ery)
     tr.append_scalars(val_abc)
     tr.append_point(c_rx)
     tr.append_point(c_ry)
@@ -231,7 +297,7 @@ def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
     x_c = tr.challenge_scalar()
     h_r, phi_r = G.loglookup_prove(q_row, t_row, freq_r, x_r)
     h_c, phi_c = G.loglookup_prove(q_col, t_col, freq_c, x_c)
-    comms = [O.pst_commit(ck, p) for p in (h_r[0], h_r[1], h_c[0], h_c[1])]
+    comms = [commit(ck, p) for p in (h_r[0], h_r[1], h_c[0], h_c[1])]
     for c in comms:
         tr.append_point(c)
     z_r = tr.challenge_vector(qv)
@@ -241,7 +307,10 @@ def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
     polys, products = [erx, ery, val_m], [(1, [0, 1, 2])]
     G.append_sumcheck_polys(polys, products, h_r, phi_r, freq_r, 0, z_r, lam_r)
     G.append_sumcheck_polys(polys, products, h_c, phi_c, freq_c, 0, z_c, lam_c)
-    msgs, point, _finals = G.distributed_sumcheck(polys, products, tr)
+    if kpw:
+        msgs, point, _finals = G.distributed_sumcheck_split(polys, products, tr, kpw)
+    else:
+        msgs, point, _finals = G.distributed_sumcheck(polys, products, tr)
     eta = tr.challenge_scalar()
     committed = [h_r[0], h_r[1], h_c[0], h_c[1], erx, ery, val_a, val_b, val_c]
     public = [freq_r, q_row, t_row, freq_c, q_col, t_col]
@@ -250,8 +319,21 @@ def lookup_round(seed, nv, entries, eq_rx, eq_ry, abc, fin2, tr):
     for p in committed:
         agg = [(a + w * b) % R for a, b in zip(agg, p)]
         w = w * eta % R
-    proofs, val = O.pst_open(ck, agg, point)
-    evals = [O.pst_evaluate_le(p, point) for p in committed + public]
+    if kpw:
+        proofs, val = split_open(ck, agg, point, kpw)
+        cn, ql = NZ >> kpw, qv - kpw
+        evals = []
+        for p_ in committed + public:  # chunk evaluations weighed with eq(point_high, j)
+            acc = 0
+            for j in range(1 << kpw):
+                w_ = 1
+                for b in range(kpw):
+                    w_ = w_ * (point[ql + b] if (j >> b) & 1 else (1 - point[ql + b])) % R
+                acc = (acc + w_ * O.pst_evaluate_le(p_[j * cn:(j + 1) * cn], point[:ql])) % R
+            evals.append(acc)
+    else:
+        proofs, val = O.pst_open(ck, agg, point)
+        evals = [O.pst_evaluate_le(p, point) for p in committed + public]
     # ---- verification (logup.rs:117-190, verifier.rs:124-150): sumcheck from the claimed sum val_m, final identity, batch opening
     expected = (abc[0] * val_abc[0] + abc[1] * val_abc[1] + abc[2] * val_abc[2]) % R
     for ev, r in zip(msgs, point):
