@@ -975,7 +975,7 @@ static g1_affine abi_to_affine(const uint64_t xy[8], int inf) {
     return a;
 }
 
-// k MSMs with per-polynomial base slices; launch sets are cut so that one set holds at most 2^28 point
+// k MSMs with per-polynomial base slices; launch sets are cut so that one set holds at most 2^28 .. 2^30 point
 // references (1 GiB of refs) and at most 64 (window table) / 4 (16 window groups) polynomials
 void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, const size_t* ns, const void* const* scalars,
                const int* kinds, size_t k, uint64_t* out_xy, int* out_inf) {
@@ -998,6 +998,23 @@ void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, co
         // cut the launch sets, then pipeline: sort(k + 1) on the side stream while accumulate(k) runs on the main one
         struct SetRange { size_t s, P; };
         std::vector<SetRange> sets;
+        // References per launch set: a quarter of the batch, so that the sort of set k + 1 still hides behind the accumulation of set
+        // k, within [2^28, 2^30] (the two sort workspaces hold 4 bytes per reference).  Measured: at 2^22 coefficients 2^30 beats 2^28
+        // by 7 % of the commit (4 instead of 16 polynomials per set paid the per-set scans and the host's wait for the fullest bucket
+        // 4 x as often); at 2^20 one 2^30 set would hold all 64 field-element polynomials and lose the overlap (+4 %).
+        // COZK_MSM_SET_REFS_LOG2 (24..31) pins the cap for A/B runs.
+        uint64_t set_refs_cap;
+        {
+            static const int pinned = getenv("COZK_MSM_SET_REFS_LOG2") ? atoi(getenv("COZK_MSM_SET_REFS_LOG2")) : 0;
+            if (pinned) set_refs_cap = 1ull << (pinned < 24 ? 24 : (pinned > 31 ? 31 : pinned));
+            else {
+                uint64_t total = 0;
+                for (size_t p = 0; p < kt; p++) total += (uint64_t)ns[t0 + p] * kind_nwin(kinds[t0 + p]);
+                set_refs_cap = total / 4;
+                if (set_refs_cap < (1ull << 28)) set_refs_cap = 1ull << 28;
+                if (set_refs_cap > (1ull << 30)) set_refs_cap = 1ull << 30;
+            }
+        }
         {
             size_t s = 0;
             while (s < kt) {
@@ -1005,7 +1022,7 @@ void msm_batch(cozk_ctx* ctx, const cozk_bases* bases, const size_t* offsets, co
                 uint64_t M = 0;
                 while (s + P < kt && P < maxP) {
                     uint64_t m = (uint64_t)ns[t0 + s + P] * kind_nwin(kinds[t0 + s + P]);
-                    if (P > 0 && M + m > (1ull << 28)) break;
+                    if (P > 0 && M + m > set_refs_cap) break;
                     M += m;
                     P++;
                 }
