@@ -545,8 +545,8 @@ static __device__ __forceinline__ void stage_in_rows(const char* __restrict__ g,
     }
     stage_fence();  // the window is free again once every lane has its row
 }
-// the 4 elements of this lane -> g + lane * 128 (rows of a wave are contiguous on the way out)
-static __device__ __forceinline__ void stage_out_rows(char* __restrict__ g, char* st, const fe in[4]) {
+// the 4 elements of this lane -> g + lane * row_stride (bytes)
+static __device__ __forceinline__ void stage_out_rows(char* __restrict__ g, char* st, const fe in[4], size_t row_stride = 128) {
     const int lane = threadIdx.x & 63, piece = lane & 7, sub = lane >> 3;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -556,7 +556,7 @@ static __device__ __forceinline__ void stage_out_rows(char* __restrict__ g, char
     stage_fence();
 #pragma unroll
     for (int k = 0; k < 8; k++)
-        *reinterpret_cast<uint4*>(g + (size_t)(8 * k + sub) * 128 + 16 * piece) = *reinterpret_cast<const uint4*>(st + (8 * k + sub) * ST_ROW + 16 * piece);
+        *reinterpret_cast<uint4*>(g + (size_t)(8 * k + sub) * row_stride + 16 * piece) = *reinterpret_cast<const uint4*>(st + (8 * k + sub) * ST_ROW + 16 * piece);
     stage_fence();
 }
 
