@@ -319,11 +319,12 @@ def run_rank(args):
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE) of this same
     # command: bench.py cannot run rocprofv3 on itself, so the figure is a committed measurement, tagged with its source
     try:
-        pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_hbm.json")))
+        hbm_file = next(f for f in ("r3_pmc_hbm.json", "r2_pmc_hbm.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        pm = json.load(open(os.path.join(ROOT, "profiles", hbm_file)))
         pmc = next(v for k, v in pm["kernels"].items() if "k_msm_accum0_f9" in k)
         if log_n == 20 and world == 1:
             roofline["traffic"] = int((pmc["FETCH_SIZE_KB_per_launch"] + pmc["WRITE_SIZE_KB_per_launch"]) * 1024)
-            roofline["traffic_source"] = "profiles/r2_pmc_hbm.json (%s); NOT measured in this run" % pm.get("measured_at", "rocprofv3 --pmc passes of this command")
+            roofline["traffic_source"] = "profiles/%s (%s); NOT measured in this run" % (hbm_file, pm.get("measured_at", "rocprofv3 --pmc passes of this command"))
     except Exception:
         pass
     # per-kernel rooflines of the HBM-bound kernels of the polynomial seam (HIP events on the context's streams;
@@ -355,13 +356,14 @@ def run_rank(args):
                                    "micro-benchmark, best of 7 in this run"}
     # how full the vector-issue slots of the gather kernel are: SQ counters of a separate rocprofv3 --pmc pass (committed, tagged)
     try:
-        sq = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_sq.json")))
+        sq_file = next(f for f in ("r3_pmc_sq.json", "r2_pmc_sq.json") if os.path.exists(os.path.join(ROOT, "profiles", f)))
+        sq = json.load(open(os.path.join(ROOT, "profiles", sq_file)))
         ks = next(v for k, v in sq["kernels"].items() if "k_msm_accum0_f9" in k)
         if log_n == 20 and world == 1:
             roofline["int_alu"]["valu_issue_utilisation"] = ks["derived"]["valu_issue_utilisation_same_pass"]
             roofline["int_alu"]["lane_utilisation"] = ks["derived"]["lane_utilisation"]
             roofline["int_alu"]["valu_instructions_per_point_add"] = round(ks["SQ_INSTS_VALU"] * 64.0 / (prof["point_adds"] / launches), 1)
-            roofline["int_alu"]["counters_source"] = "profiles/r2_pmc_sq.json (%s); NOT measured in this run" % sq.get("measured_at", "")
+            roofline["int_alu"]["counters_source"] = "profiles/%s (%s); NOT measured in this run" % (sq_file, sq.get("measured_at", ""))
     except Exception:
         pass
 
