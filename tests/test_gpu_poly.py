@@ -106,7 +106,7 @@ def test_eq_evals_and_spliteq(cozk, ctx):
 
 
 @pytest.mark.parametrize("mode", ["rep3", "plain"])
-@pytest.mark.parametrize("length", [2, 4, 6, 8, 12, 64, 96, 1024, 2048 + 8])
+@pytest.mark.parametrize("length", [2, 4, 6, 8, 12, 64, 96, 1024, 2048 + 8, 4096 + 24, 3 * 4096 + 40, 1 << 14])
 def test_layer_bind_and_cubic_all_rounds(cozk, ctx, mode, length):
     """runs every sumcheck round of one layer: compute_cubic (nested Dao-Thaler case while E1 is
     unbound, then the linear-time case), bind, eq bind -- comparing each message with the oracle."""
@@ -138,11 +138,12 @@ def test_layer_bind_and_cubic_all_rounds(cozk, ctx, mode, length):
 
 
 @pytest.mark.parametrize("mode", ["rep3", "plain"])
-@pytest.mark.parametrize("length", [4, 6, 96, 2048 + 8, 1 << 15, (1 << 15) + 12])
+@pytest.mark.parametrize("length", [4, 6, 96, 2048 + 8, 8192 + 72, 1 << 15, (1 << 15) + 12, 3 * (1 << 14) + 520])
 def test_layer_round_fused_equals_separate_calls(cozk, ctx, mode, length):
     """cozk_layer_round (bind + eq bind + compute_cubic per call; single-launch kernel for layers <= 8192 elements,
-    so the two larger sizes cross from the separate-kernel path into it) gives the same round messages and the
-    same bound layer as the separate calls; the small sizes are also checked against the oracle"""
+    so the larger sizes cross from the separate-kernel path into it) gives the same round messages and the
+    same bound layer as the separate calls, and the oracle's.  The larger sizes run the 9 x 29 kernels with the LDS-staged
+    whole-line accesses; the ragged ones mix staged waves with the direct path of the last, partial wave."""
     rng = O.SplitMix64(length * 5 + (mode == "plain"))
     coeffs = _shares(rng, length, mode)
     nodes = (length + 1) // 2
@@ -151,7 +152,7 @@ def test_layer_round_fused_equals_separate_calls(cozk, ctx, mode, length):
     fused = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
     sep = cozk.Rep3DenseInterleavedPolynomial.new(ctx, coeffs)
     eq_f, eq_s = cozk.SplitEqPolynomial(ctx, w), cozk.SplitEqPolynomial(ctx, w)
-    small = length <= 4096
+    small = True  # every size against the oracle (Python: ~0.1 s per round at 2^15)
     ref, ref_eq = list(coeffs), O.SplitEq(w)
     r = None
     for _ in range(nv):
