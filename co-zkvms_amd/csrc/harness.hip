@@ -22,7 +22,8 @@ static uint64_t sm_next_host(uint64_t& s) {
     return z ^ (z >> 31);
 }
 // element i of the stream `seed` (same generator as cozk_vec_fill_random / oracle synthetic_fr)
-static fe synthetic_fr_host(uint64_t seed, uint64_t i) {
+// max_bits in 1..253 keeps the low bits of the canonical value (cozk_vec_fill_random's max_bits, pyref.synthetic_fr's)
+static fe synthetic_fr_host(uint64_t seed, uint64_t i, int max_bits = 0) {
     uint64_t s = seed + i * 0xD1342543DE82EF95ull;
     fe v;
     for (;;) {
@@ -32,6 +33,13 @@ static fe synthetic_fr_host(uint64_t seed, uint64_t i) {
         v.l[4] = (uint32_t)w2; v.l[5] = (uint32_t)(w2 >> 32);
         v.l[6] = (uint32_t)w3; v.l[7] = (uint32_t)(w3 >> 32);
         if (!Fr::geq_mod(v)) break;
+    }
+    if (max_bits > 0 && max_bits < 254) {
+        for (int k = 0; k < 8; k++) {
+            int lo = 32 * k;
+            if (max_bits <= lo) v.l[k] = 0;
+            else if (max_bits < lo + 32) v.l[k] &= (1u << (max_bits - lo)) - 1u;
+        }
     }
     return Fr::to_mont(v);
 }
@@ -140,12 +148,12 @@ static VecH vec_binop(cozk_ctx* ctx, int op, const VecH& a, const VecH& b) {
 // share components of the synthetic secret vector stream(seed) through the engine's witness scatter
 // (cozk_rep3_share_vec: t0 = PRF(k0, i), t1 = PRF(k1, i), t2 = v - t0 - t1; P0 = (t0, t2), P1 = (t1, t0), P2 = (t2, t1);
 // arithmetic.rs:21-33) with the harness keys (seed, 101) and (seed, 102)
-static void make_share_vectors(cozk_ctx* ctx, size_t n, uint64_t seed, int party, int mode, VecH& a, VecH& b) {
+static void make_share_vectors(cozk_ctx* ctx, size_t n, uint64_t seed, int party, int mode, VecH& a, VecH& b, int max_bits = 0) {
     if (mode == COZK_MODE_PLAIN) {
-        a = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
+        a = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, max_bits);
         return;
     }
-    VecH v = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, 0);
+    VecH v = make_vec_random(ctx, n, COZK_SCALAR_FR, seed, max_bits);
     uint8_t k0[COZK_PRF_KEY_BYTES], k1[COZK_PRF_KEY_BYTES];
     harness_prf_key(seed, 101, k0);
     harness_prf_key(seed, 102, k1);

@@ -71,6 +71,7 @@ struct cozk_flow {
     std::vector<std::vector<fe>> clear;  // per committed polynomial
     std::vector<int> is_public, pub_bytes;
     std::vector<uint64_t> device_stream;  // != 0: the column is the seeded stream of this seed, generated on the device (no host copy)
+    std::vector<int> device_bits;         // ... masked to this many bits (cfg.small_witness), 0 = full width
     std::vector<size_t> lens;
     std::vector<std::vector<uint64_t>> bc_table_clear, subtables_clear;
     std::vector<fe> io_range_clear, v_io_clear;
@@ -186,27 +187,31 @@ void flow_build_clear(cozk_flow* h) {
         for (unsigned k = 0; k < nt; k++) ts.emplace_back([&, k] { body(n * k / nt, n * (k + 1) / nt); });
         for (auto& t : ts) t.join();
     };
-    auto sh = [&](int idx, uint64_t s, size_t n) {
+    // cfg.small_witness: the widths a real trace gives these columns (0 = uniform field elements, see include/cozk.h)
+    const int cnt_bits = c.small_witness ? c.log_n : 0, val_bits = c.small_witness ? 32 : 0;
+    h->device_bits.assign((size_t)ix.count, 0);
+    auto sh = [&](int idx, uint64_t s, size_t n, int bits) {
         std::vector<fe>& col = h->clear[(size_t)idx];
         col.resize(n);
         par_for(n, [&](size_t lo, size_t hi) {
-            for (size_t i = lo; i < hi; i++) col[i] = synthetic_fr_host(s, i);
+            for (size_t i = lo; i < hi; i++) col[i] = synthetic_fr_host(s, i, bits);
         });
     };
-    auto dev = [&](int idx, uint64_t s, size_t n) {
+    auto dev = [&](int idx, uint64_t s, size_t n, int bits) {
         h->device_stream[(size_t)idx] = s;
+        h->device_bits[(size_t)idx] = bits;
         h->lens[(size_t)idx] = n;
     };
     pub(ix.bc_t_read, 31, N, 20);
     pub(ix.bc_t_final, 32, B, 20);
     for (int k = 0; k < 4; k++) pub(ix.rw_t_read + k, 41 + (uint64_t)k, N, 20);
-    sh(ix.rw_v_init, seed + 45000, MEM);
-    sh(ix.rw_v_final, seed + 46000, MEM);
+    sh(ix.rw_v_init, seed + 45000, MEM, val_bits);
+    sh(ix.rw_v_final, seed + 46000, MEM, val_bits);
     pub(ix.rw_t_final, 47, MEM, 20);
     for (int m = 0; m < c.n_mem; m++) {
-        dev(ix.read_cts + m, seed + 11000ull * (uint64_t)(m + 1), N);
-        sh(ix.E + m, seed + 9000ull * (uint64_t)(m + 1), N);
-        dev(ix.final_cts + m, seed + 13000ull * (uint64_t)(m + 1), M);
+        dev(ix.read_cts + m, seed + 11000ull * (uint64_t)(m + 1), N, cnt_bits);
+        sh(ix.E + m, seed + 9000ull * (uint64_t)(m + 1), N, val_bits);
+        dev(ix.final_cts + m, seed + 13000ull * (uint64_t)(m + 1), M, cnt_bits);
     }
     static const int tab_bits[6] = {20, 32, 6, 6, 6, 12};
     h->bc_table_clear.assign(6, std::vector<uint64_t>(B));
@@ -276,7 +281,7 @@ void flow_setup_party(cozk_flow* h, FlowParty& ps) {
     for (int idx = 0; idx < h->ix.count; idx++) {
         if (h->device_stream[(size_t)idx]) {  // a seeded stream: generated and shared on the device (harness.hip make_share_vectors)
             VecH a, b;
-            make_share_vectors(ctx, h->lens[(size_t)idx], h->device_stream[(size_t)idx], ps.party, c.mode, a, b);
+            make_share_vectors(ctx, h->lens[(size_t)idx], h->device_stream[(size_t)idx], ps.party, c.mode, a, b, h->device_bits[(size_t)idx]);
             cozk_poly* p = nullptr;
             rc_check(cozk_poly_create(ctx, c.mode, a.h, b.h, &p), ctx, "poly_create");
             ps.polys.push_back(PolyH(p));

@@ -8,7 +8,7 @@ from . import _lib as L
 class FlowConfig(ctypes.Structure):
     _fields_ = [("mode", ctypes.c_int), ("log_n", ctypes.c_int), ("log_m", ctypes.c_int), ("log_b", ctypes.c_int), ("log_mem", ctypes.c_int),
                 ("n_mem", ctypes.c_int), ("n_subtables", ctypes.c_int), ("devices", ctypes.c_int * 3), ("seed", ctypes.c_uint64),
-                ("precompute", ctypes.c_int)]
+                ("precompute", ctypes.c_int), ("small_witness", ctypes.c_int)]
 
 
 class FlowResult(ctypes.Structure):
@@ -42,7 +42,7 @@ def _decl():
 
 
 class FlowHarness:
-    def __init__(self, mode="plain", log_n=4, log_m=3, log_b=3, log_mem=3, n_mem=6, n_subtables=3, devices=(0, 0, 0), seed=1, precompute=1):
+    def __init__(self, mode="plain", log_n=4, log_m=3, log_b=3, log_mem=3, n_mem=6, n_subtables=3, devices=(0, 0, 0), seed=1, precompute=1, small_witness=0):
         self._l = _decl()
         cfg = FlowConfig()
         cfg.mode = L.MODE_PLAIN if mode == "plain" else L.MODE_REP3
@@ -51,6 +51,7 @@ class FlowHarness:
         cfg.devices = (ctypes.c_int * 3)(*devices)
         cfg.seed = seed
         cfg.precompute = precompute
+        cfg.small_witness = small_witness
         h = _vp()
         rc = self._l.cozk_flow_create(ctypes.byref(cfg), ctypes.byref(h))
         self.h = h

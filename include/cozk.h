@@ -773,6 +773,10 @@ typedef struct cozk_flow_config {
     int devices[3];
     uint64_t seed;
     int precompute;   /* the SRS window table (cozk_bases_upload) */
+    int small_witness; /* 0: read / final counters, E polynomials and memory values are uniform field elements -- what a Rep3 party
+                        * commits to (its share of every value is uniform) and an upper bound for a plain prover; 1: they are as wide
+                        * as a real trace makes them (counters < 2^log_n, subtable entries and memory words 32 bits), so a PLAIN
+                        * prover's commitments fill 2 of the 16 windows; Rep3 shares stay uniform either way */
 } cozk_flow_config;
 typedef struct cozk_flow_result {
     int verified;

@@ -71,19 +71,22 @@ def build_witness(cfg):
     r1 = J.synthetic_columns(seed, N)
     W["r1cs"] = [Poly(J.NAMES[v], r1[v], J.IS_PUBLIC[v], seed + 100 * (v + 1), np_) for v in range(J.NUM_INPUTS)]
     pub = lambda name, off, n, bits: Poly(name, O.synthetic_small(seed + off, n, bits), True, 0, np_)
-    sh = lambda name, s, n: Poly(name, O.synthetic_fr(s, n), False, s, np_)
+    # cfg["small_witness"]: counters < 2^log_n, subtable entries and memory words 32 bits (include/cozk.h); default: uniform
+    small = int(cfg.get("small_witness", 0))
+    cnt_bits, val_bits = (cfg["log_n"], 32) if small else (0, 0)
+    sh = lambda name, s, n, bits=0: Poly(name, O.synthetic_fr(s, n, bits), False, s, np_)
     W["bc_t_read"] = pub("bc_t_read", 31, N, 20)
     W["bc_t_final"] = pub("bc_t_final", 32, B, 20)
     # the bytecode table (preprocessing.v_init_final): address, bitflags, rd, rs1, rs2, imm
     W["bc_table"] = [O.synthetic_small(seed + 33, B, 20), O.synthetic_small(seed + 34, B, 32), O.synthetic_small(seed + 35, B, 6),
                      O.synthetic_small(seed + 36, B, 6), O.synthetic_small(seed + 37, B, 6), O.synthetic_small(seed + 38, B, 12)]
     W["rw_t_read"] = [pub("rw_t_read_%s" % k, 41 + i, N, 20) for i, k in enumerate(("rd", "rs1", "rs2", "ram"))]
-    W["rw_v_init"] = sh("rw_v_init", seed + 45000, MEM)
-    W["rw_v_final"] = sh("rw_v_final", seed + 46000, MEM)
+    W["rw_v_init"] = sh("rw_v_init", seed + 45000, MEM, val_bits)
+    W["rw_v_final"] = sh("rw_v_final", seed + 46000, MEM, val_bits)
     W["rw_t_final"] = pub("rw_t_final", 47, MEM, 20)
-    W["read_cts"] = [sh("read_cts_%d" % m, seed + 11000 * (m + 1), N) for m in range(n_mem)]
-    W["E"] = [sh("E_%d" % m, seed + 9000 * (m + 1), N) for m in range(n_mem)]
-    W["final_cts"] = [sh("final_cts_%d" % m, seed + 13000 * (m + 1), M) for m in range(n_mem)]
+    W["read_cts"] = [sh("read_cts_%d" % m, seed + 11000 * (m + 1), N, cnt_bits) for m in range(n_mem)]
+    W["E"] = [sh("E_%d" % m, seed + 9000 * (m + 1), N, val_bits) for m in range(n_mem)]
+    W["final_cts"] = [sh("final_cts_%d" % m, seed + 13000 * (m + 1), M, cnt_bits) for m in range(n_mem)]
     W["subtables"] = [O.synthetic_small(seed + 15000 * (s + 1), M, 32) for s in range(n_sub)]
     instrs = L.instr_table(n_mem)
     iflags = [r1[J.IDX["I_" + nm]] for nm in J.INSTRUCTIONS]

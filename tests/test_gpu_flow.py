@@ -30,7 +30,8 @@ def _split(blob, ref):
 @pytest.mark.parametrize("mode", ["plain", "rep3"])
 @pytest.mark.parametrize("cfg", [dict(log_n=2, log_m=1, log_b=1, log_mem=2, n_mem=3, n_subtables=2, seed=3),
                                  dict(log_n=3, log_m=3, log_b=2, log_mem=3, n_mem=6, n_subtables=3, seed=5),
-                                 dict(log_n=5, log_m=3, log_b=4, log_mem=4, n_mem=9, n_subtables=4, seed=7)])
+                                 dict(log_n=5, log_m=3, log_b=4, log_mem=4, n_mem=9, n_subtables=4, seed=7),
+                                 dict(log_n=4, log_m=3, log_b=3, log_mem=3, n_mem=6, n_subtables=3, seed=11, small_witness=1)])
 def test_flow_proof_bit_identical_to_the_oracle(cozk, mode, cfg):
     FL = importlib.import_module("co-zkvms_amd.flow")
     h = FL.FlowHarness(mode=mode, **cfg)

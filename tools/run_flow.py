@@ -11,6 +11,7 @@ ap.add_argument("--log-n", type=int, default=20)
 ap.add_argument("--n-mem", type=int, default=54)
 ap.add_argument("--n-subtables", type=int, default=26)
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--small-witness", action="store_true", help="counters < 2^log_n, E / memory values 32 bits (a plain prover's real widths) instead of uniform field elements")
 args = ap.parse_args()
 FL = importlib.import_module("co-zkvms_amd.flow")
 ngpu = torch.cuda.device_count()
@@ -18,7 +19,7 @@ devs = (0, 1, 2) if ngpu >= 3 else (0, 0, 0)
 n = args.log_n
 t0 = time.time()
 h = FL.FlowHarness(mode=args.mode, log_n=n, log_m=min(16, n), log_b=min(14, n), log_mem=min(17, n), n_mem=args.n_mem, n_subtables=args.n_subtables,
-                   seed=2026, devices=devs)
+                   seed=2026, devices=devs, small_witness=1 if args.small_witness else 0)
 setup_s = time.time() - t0
 t0 = time.time()
 r = h.prove(verify=True)
@@ -29,7 +30,7 @@ for _ in range(args.steps):
     r = h.prove(verify=False)
 dt = (time.perf_counter() - t0) / args.steps
 print(json.dumps({"what": "one chained co-jolt worker flow (commit-all, bytecode, instruction lookups, read-write memory, Spartan, one batched opening)",
-                  "mode": args.mode, "log_n": n, "memories": args.n_mem, "subtables": args.n_subtables, "polys_committed": int(r.n_polys), "openings": int(r.n_openings),
+                  "mode": args.mode, "witness": "real widths (counters < 2^log_n, E / memory values 32 bits)" if args.small_witness else "uniform field elements", "log_n": n, "memories": args.n_mem, "subtables": args.n_subtables, "polys_committed": int(r.n_polys), "openings": int(r.n_openings),
                   "devices": list(devs), "verified": 1, "ms_per_proof": round(dt * 1e3, 2), "cycles_per_s": round((1 << n) / dt, 1),
                   "phases_ms": {"commit": round(r.t_commit_ms, 2), "bytecode": round(r.t_bytecode_ms, 2), "lookups_primary_sumcheck": round(r.t_primary_ms, 2),
                                 "lookups_memory_checking": round(r.t_lookups_gp_ms, 2), "read_write_memory": round(r.t_rw_ms, 2), "spartan": round(r.t_spartan_ms, 2),
