@@ -1216,12 +1216,17 @@ __global__ void __launch_bounds__(PT) k_eq_expand(const fe* __restrict__ in, fe*
 
 // whole EqPolynomial::evals table in one launch (one workgroup; tables here are <= 2^13 entries:
 // the two halves of a split-eq): level j doubles the table in place from the top index down
-__global__ void __launch_bounds__(1024) k_eq_build(const fe* __restrict__ r, int nv, fe* __restrict__ out) {
+// The point travels in the kernel arguments (<= 13 x 32 B): a grand product builds ~220 of these tables per chained proof, and a
+// host-to-device copy of the point plus the stream synchronisation that protects the caller's buffer cost more than the kernel.
+struct EqBuildPoint {
+    fe r[13];
+};
+__global__ void __launch_bounds__(1024) k_eq_build(EqBuildPoint pt, int nv, fe* __restrict__ out) {
     if (threadIdx.x == 0) fe_store(out, Fr::one());
     __syncthreads();
     size_t n = 1;
     for (int j = 0; j < nv; j++) {
-        fe rj = fe_load(r + j);
+        fe rj = pt.r[j];
         // read phase, then write phase: entry i expands to (2i, 2i+1)
         fe e[8];
         int cnt = 0;
@@ -1280,17 +1285,12 @@ static fe* result_slot(cozk_ctx* ctx, size_t k) { return (fe*)ctx_pinned(ctx, k 
 // build an eq table on device: out (len 2^nv) from point r (host), big-endian
 static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp) {
     if (nv <= 13) {
-        // small table: one launch; the point travels through `tmp` (tmp has >= 2^nv entries; nv >= 0)
-        fe* rd = tmp;
-        if (nv > 0) {
-            if ((size_t)nv > ((size_t)1 << nv)) {  // nv = 1..3: 2^nv may be smaller than nv entries of scratch
-                ctx->scratch.reserve(64 * sizeof(fe));
-                rd = ctx->scratch.as<fe>();
-            }
-            HIP_TRY(hipMemcpyAsync(rd, r, (size_t)nv * sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
-            HIP_TRY(hipStreamSynchronize(ctx->stream));  // r is caller-owned host memory
-        }
-        k_eq_build<<<1, 1024, 0, ctx->stream>>>(rd, nv, out);
+        // small table: one launch, the point in the kernel arguments
+        (void)tmp;
+        EqBuildPoint pt;
+        for (int j = 0; j < nv; j++) pt.r[j] = r[j];
+        for (int j = nv; j < 13; j++) pt.r[j] = Fr::zero();
+        k_eq_build<<<1, 1024, 0, ctx->stream>>>(pt, nv, out);
         HIP_TRY(hipGetLastError());
         return;
     }
