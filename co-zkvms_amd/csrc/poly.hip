@@ -979,9 +979,14 @@ __global__ void __launch_bounds__(PT) k_mul_vec_local(const fe* __restrict__ xa,
 // read_write_memory/worker.rs:149-164): evaluations at x = 0, 2, .., degree of
 // sum_i prod_j P_j(x; i) with HighToLow pairs (i, i + half) (sumcheck_evals, dense_mlpoly.rs:113-147).
 // partial[e * gridDim.x + block]; shared factor enters as (a + b), TWO_INV applied by the finisher.
+struct ProdRoundPtrs {  // <= 4 factors: the pointer table travels in the kernel arguments (no upload + stream sync per round)
+    const fe* a[4];
+    const fe* b[4];
+};
 template <int NC, int M>
-__global__ void __launch_bounds__(PT) k_prod_round(const fe* const* __restrict__ pa, const fe* const* __restrict__ pb,
-                                                int shared_idx, size_t half, int degree, fe* __restrict__ partial) {
+__global__ void __launch_bounds__(PT) k_prod_round(ProdRoundPtrs tab, int shared_idx, size_t half, int degree, fe* __restrict__ partial) {
+    const fe* const* pa = tab.a;
+    const fe* const* pb = tab.b;
     __shared__ fe sh4[4];
     fe acc[4];
     for (int e = 0; e < 4; e++) acc[e] = Fr::zero();
@@ -1482,7 +1487,7 @@ int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys
         const fe** db = da + k;
         size_t* dl = (size_t*)(db + k);
         fe* partial = (fe*)(((uintptr_t)(dl + k) + 31) & ~(uintptr_t)31);
-        fe* res = partial + k * gx;
+        fe* res = result_slot(ctx, k);  // pinned: no device-to-host copy behind the finishing kernel
         HIP_TRY(hipMemcpyAsync(da, ha.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(db, hb.data(), k * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(hipMemcpyAsync(dl, hl.data(), k * sizeof(size_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1512,7 +1517,7 @@ int cozk_poly_dot_product_with_public(cozk_ctx* ctx, const cozk_poly* p, const c
         if (gx > 512) gx = 512;
         ctx->scratch.reserve((2 * gx + 2) * sizeof(fe));
         fe* partial = ctx->scratch.as<fe>();
-        fe* res = partial + 2 * gx;
+        fe* res = result_slot(ctx, 2);
         int nc = p->mode == COZK_MODE_REP3 ? 2 : 1;
         if (nc == 2) k_poly_dot_public<2><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
         else k_poly_dot_public<1><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
@@ -1762,15 +1767,15 @@ int cozk_prod_sumcheck_evals(cozk_ctx* ctx, const cozk_poly* const* polys, size_
         size_t half = len / 2;
         unsigned gx = grid_capped(half);
         if (gx > 512) gx = 512;
-        ctx->scratch.reserve(8 * sizeof(void*) + (4 * (size_t)gx + 4) * sizeof(fe) + 64);
-        const fe** da = (const fe**)ctx->scratch.p;
-        const fe** db = da + 4;
-        fe* partial = (fe*)(((uintptr_t)(db + 4) + 31) & ~(uintptr_t)31);
-        fe* res = partial + 4 * (size_t)gx;
-        HIP_TRY(hipMemcpyAsync(da, ha, 4 * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipMemcpyAsync(db, hb, 4 * sizeof(void*), hipMemcpyHostToDevice, ctx->stream));
-        HIP_TRY(hipStreamSynchronize(ctx->stream));
-#define PROD_LAUNCH(NCV, MV) k_prod_round<NCV, MV><<<gx, PT, 0, ctx->stream>>>(da, db, shared, half, degree, partial)
+        ctx->scratch.reserve((4 * (size_t)gx + 4) * sizeof(fe) + 64);
+        fe* partial = ctx->scratch.as<fe>();
+        fe* res = result_slot(ctx, 4);
+        ProdRoundPtrs tab;
+        for (int j = 0; j < 4; j++) {
+            tab.a[j] = ha[j];
+            tab.b[j] = hb[j];
+        }
+#define PROD_LAUNCH(NCV, MV) k_prod_round<NCV, MV><<<gx, PT, 0, ctx->stream>>>(tab, shared, half, degree, partial)
         if (shared >= 0) {
             switch (m) { case 1: PROD_LAUNCH(2, 1); break; case 2: PROD_LAUNCH(2, 2); break; case 3: PROD_LAUNCH(2, 3); break; default: PROD_LAUNCH(2, 4); }
         } else {
@@ -1798,7 +1803,7 @@ int cozk_spartan_first_round(cozk_ctx* ctx, const cozk_poly* za, const cozk_poly
         if (gx > 512) gx = 512;
         ctx->scratch.reserve((8 * (size_t)gx + 8) * sizeof(fe));
         fe* partial = ctx->scratch.as<fe>();
-        fe* res = partial + 8 * (size_t)gx;
+        fe* res = result_slot(ctx, 8);
         if (za->mode == COZK_MODE_REP3)
             k_spartan_first<2><<<gx, PT, 0, ctx->stream>>>(poly_a(za), poly_b(za), poly_a(zb), poly_b(zb), poly_a(zc), poly_b(zc), poly_a(pub), half, partial);
         else
@@ -1827,7 +1832,7 @@ int cozk_spartan_second_round(cozk_ctx* ctx, const cozk_poly* z, const cozk_poly
         if (gx > 512) gx = 512;
         ctx->scratch.reserve((6 * (size_t)gx + 6) * sizeof(fe));
         fe* partial = ctx->scratch.as<fe>();
-        fe* res = partial + 6 * (size_t)gx;
+        fe* res = result_slot(ctx, 6);
         int nc = z->mode == COZK_MODE_REP3 ? 2 : 1;
         fe c0 = fe_from_u64x4(coef), c1 = fe_from_u64x4(coef + 4), c2 = fe_from_u64x4(coef + 8);
         if (nc == 2) k_spartan_second<2><<<gx, PT, 0, ctx->stream>>>(poly_a(z), poly_b(z), poly_a(a), poly_a(b), poly_a(c), c0, c1, c2, half, partial);
