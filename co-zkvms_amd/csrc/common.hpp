@@ -1,5 +1,31 @@
 // Shared host-side plumbing for libcozk: context, error handling, device buffers.
 #pragma once
+#ifdef COZK_COUNT_COPIES
+#include <hip/hip_runtime.h>
+#include <map>
+#include <string>
+#include <cstdio>
+#include <mutex>
+struct CozkCopyCounter {
+    std::map<std::string, unsigned long> m;
+    std::mutex mu;
+    ~CozkCopyCounter() {
+        for (auto& kv : m) fprintf(stderr, "[copies] %8lu  %s\n", kv.second, kv.first.c_str());
+    }
+};
+inline CozkCopyCounter& cozk_copy_counter() { static CozkCopyCounter c; return c; }
+inline void cozk_count_copy(const char* what, const char* f, int l) {
+    auto& c = cozk_copy_counter();
+    std::lock_guard<std::mutex> g(c.mu);
+    const char* b = f;
+    for (const char* p = f; *p; p++) if (*p == '/') b = p + 1;
+    c.m[std::string(what) + " " + b + ":" + std::to_string(l)]++;
+}
+#define hipMemcpyAsync(...) (cozk_count_copy("memcpy", __FILE__, __LINE__), hipMemcpyAsync(__VA_ARGS__))
+#define hipStreamSynchronize(...) (cozk_count_copy("sync", __FILE__, __LINE__), hipStreamSynchronize(__VA_ARGS__))
+#define hipMemsetAsync(...) (cozk_count_copy("memset", __FILE__, __LINE__), hipMemsetAsync(__VA_ARGS__))
+#endif
+
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

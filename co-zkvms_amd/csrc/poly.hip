@@ -1221,6 +1221,13 @@ __global__ void __launch_bounds__(PT) k_eq_expand(const fe* __restrict__ in, fe*
 
 // whole EqPolynomial::evals table in one launch (one workgroup; tables here are <= 2^13 entries:
 // the two halves of a split-eq): level j doubles the table in place from the top index down
+__global__ void k_store_fe(fe* out, fe v) { fe_store(out, v); }
+__global__ void k_store_u32s(uint32_t* out, const uint32_t* __restrict__ in0, const uint32_t* __restrict__ in1, int n0, size_t stride0) {
+    // out[i] = in0[i * stride0] for i < n0, then out[n0] = *in1 (small gathers into a pinned slot instead of strided device-to-host copies)
+    int i = threadIdx.x;
+    if (i < n0) out[i] = in0[(size_t)i * stride0];
+    if (i == n0 && in1) out[n0] = *in1;
+}
 // The point travels in the kernel arguments (<= 13 x 32 B): a grand product builds ~220 of these tables per chained proof, and a
 // host-to-device copy of the point plus the stream synchronisation that protects the caller's buffer cost more than the kernel.
 struct EqBuildPoint {
@@ -1254,34 +1261,34 @@ __global__ void __launch_bounds__(1024) k_eq_build(EqBuildPoint pt, int nv, fe* 
 static fe* dev_alloc_fe(size_t n) { return (fe*)ctx_dev_alloc(t_cur_ctx, (n ? n : 1) * sizeof(fe)); }
 
 // copy k small results from device scratch to host (sync)
-static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
-    fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
-    if (d != pin) {
-        HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+// the stream's work up to here has finished: a stream memory write of a sequence number + a host spin on that pinned word replaces
+// hipStreamSynchronize's event / interrupt path (tens of microseconds) with a cache-line hand-off (COZK_SYNC_ROUNDS: the blocking wait)
+static void stream_drain_by_flag(cozk_ctx* ctx) {
+    static const bool use_flag = getenv("COZK_SYNC_ROUNDS") == nullptr;
+    if (!use_flag) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
-    } else {
-        // Round results are written by the finishing kernel straight into pinned (device-visible) host memory, so
-        // there is nothing to copy -- only the stream to drain, ~270 times per grand product.  A stream memory
-        // write of a sequence number behind the kernel + a host spin on that word replaces hipStreamSynchronize's
-        // event/interrupt path (tens of microseconds) with a cache-line hand-off.
-        static const bool use_flag = getenv("COZK_SYNC_ROUNDS") == nullptr;
-        if (use_flag) {
-            if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocDefault));
-            uint32_t seq = ++ctx->round_seq;
-            HIP_TRY(hipStreamWriteValue32(ctx->stream, (void*)ctx->round_flag, seq, 0));
-            volatile uint32_t* f = ctx->round_flag;
-            uint64_t spins = 0;
-            while (*f != seq) {
-                __builtin_ia32_pause();
-                if (++spins > (1ull << 22)) {  // ~10 ms without news: fall back to the blocking wait (also surfaces errors)
-                    HIP_TRY(hipStreamSynchronize(ctx->stream));
-                    break;
-                }
-            }
-        } else {
+        return;
+    }
+    if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocDefault));
+    uint32_t seq = ++ctx->round_seq;
+    HIP_TRY(hipStreamWriteValue32(ctx->stream, (void*)ctx->round_flag, seq, 0));
+    volatile uint32_t* f = ctx->round_flag;
+    uint64_t spins = 0;
+    while (*f != seq) {
+        __builtin_ia32_pause();
+        if (++spins > (1ull << 22)) {  // ~10 ms without news: fall back to the blocking wait (also surfaces errors)
             HIP_TRY(hipStreamSynchronize(ctx->stream));
+            break;
         }
     }
+}
+// copy k small results to the host.  Round results are written by the finishing kernel straight into pinned (device-visible) host
+// memory (d == the pinned slot): nothing to copy, only the stream to drain, ~270 times per grand product; anything else is copied
+// into the pinned slot first.
+static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
+    fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
+    if (d != pin) HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+    stream_drain_by_flag(ctx);
     for (size_t i = 0; i < k; i++) h[i] = pin[i];
 }
 // where a finishing kernel should put k round results (pinned host memory, mapped into the device)
@@ -1299,11 +1306,9 @@ static void eq_evals_device(cozk_ctx* ctx, const fe* r, int nv, fe* out, fe* tmp
         HIP_TRY(hipGetLastError());
         return;
     }
-    fe one = Fr::one();
     fe* cur = (nv % 2 == 0) ? out : tmp;  // ping-pong so that the last level lands in `out`
     fe* nxt = (nv % 2 == 0) ? tmp : out;
-    HIP_TRY(hipMemcpyAsync(cur, &one, sizeof(fe), hipMemcpyHostToDevice, ctx->stream));
-    HIP_TRY(hipStreamSynchronize(ctx->stream));  // `one` lives on the stack
+    k_store_fe<<<1, 1, 0, ctx->stream>>>(cur, Fr::one());  // the value travels in the kernel arguments: no copy, no sync
     size_t n = 1;
     for (int j = 0; j < nv; j++) {
         k_eq_expand<<<grid_for(n), PT, 0, ctx->stream>>>(cur, nxt, n, r[j]);
