@@ -166,6 +166,7 @@ int cozk_ctx_destroy(cozk_ctx* ctx) {
     ctx->scratch2.release();
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     if (ctx->round_flag) (void)hipHostFree(ctx->round_flag);
+    if (ctx->finish_ticket) (void)hipFree(ctx->finish_ticket);
     if (ctx->mailbox) (void)hipHostFree(ctx->mailbox);
     if (ctx->stream2) {
         (void)hipStreamSynchronize(ctx->stream2);

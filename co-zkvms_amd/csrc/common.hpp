@@ -212,6 +212,8 @@ struct cozk_ctx {
     void* mailbox = nullptr;         // fine-grained pinned host memory shared with the resident round kernel
     uint32_t* round_flag = nullptr;  // pinned word a stream write bumps behind each round's finishing kernel
     uint32_t round_seq = 0;
+    uint32_t armed_seq = 0;           // != 0: a finishing kernel will publish this sequence number itself (fetch_fe just waits for it)
+    unsigned* finish_ticket = nullptr;  // device counter of the finishing kernel's workgroups (zero between launches)
     // timing of the dominant kernel (bench roofline): accumulated HIP-event time of the
     // bucket-accumulation launches on this stream
     bool prof_enabled = false;

@@ -132,13 +132,30 @@ __global__ void __launch_bounds__(PT) k_poly_eval_chi(const fe* const* __restric
 }
 
 // out[y] = scale * sum_x partial[y * nper + x]
+// ... and, when `pub` is armed, the LAST of its (few) workgroups publishes the round's sequence number into the pinned word the host
+// spins on: no stream memory write behind the kernel (~560 per chained proof, 3.5 us of GPU time + a launch gap each).
+struct RoundPublish {
+    unsigned* ticket;  // device counter, zero between launches; nullptr: nothing to publish
+    uint32_t* flag;    // pinned word
+    uint32_t seq;
+};
 __global__ void __launch_bounds__(PT) k_finish_sums(const fe* __restrict__ partial, unsigned nper, fe scale, int apply_scale,
-                                                 fe* __restrict__ out) {
+                                                 fe* __restrict__ out, RoundPublish pub) {
     __shared__ fe sh4[4];
     fe acc = Fr::zero();
     for (unsigned x = threadIdx.x; x < nper; x += PT) acc = Fr::add(acc, fe_load(partial + (size_t)blockIdx.x * nper + x));
     acc = fr_block_sum(acc, sh4);
-    if (threadIdx.x == 0) fe_store(out + blockIdx.x, apply_scale ? Fr::mul(acc, scale) : acc);
+    if (threadIdx.x == 0) {
+        fe_store(out + blockIdx.x, apply_scale ? Fr::mul(acc, scale) : acc);
+        if (pub.ticket) {
+            __threadfence_system();  // this workgroup's result is in host memory before its ticket
+            if (atomicAdd(pub.ticket, 1u) == gridDim.x - 1) {
+                *pub.ticket = 0;
+                __threadfence_system();
+                __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 // per-component dot product with a public vector (dot_product_with_public, dense_mlpoly.rs:228-234)
@@ -1269,7 +1286,7 @@ static void stream_drain_by_flag(cozk_ctx* ctx) {
         HIP_TRY(hipStreamSynchronize(ctx->stream));
         return;
     }
-    if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocDefault));
+    if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
     uint32_t seq = ++ctx->round_seq;
     HIP_TRY(hipStreamWriteValue32(ctx->stream, (void*)ctx->round_flag, seq, 0));
     volatile uint32_t* f = ctx->round_flag;
@@ -1282,13 +1299,40 @@ static void stream_drain_by_flag(cozk_ctx* ctx) {
         }
     }
 }
+// arm the finishing kernel's own publication of the round (COZK_FLAG_IN_FINISH=0 / COZK_SYNC_ROUNDS: not armed, fetch_fe drains the stream)
+static RoundPublish arm_round_publish(cozk_ctx* ctx) {
+    static const bool on = !(getenv("COZK_FLAG_IN_FINISH") && atoi(getenv("COZK_FLAG_IN_FINISH")) == 0) && getenv("COZK_SYNC_ROUNDS") == nullptr;
+    if (!on) return RoundPublish{nullptr, nullptr, 0};
+    if (!ctx->round_flag) HIP_TRY(hipHostMalloc((void**)&ctx->round_flag, 64, hipHostMallocMapped | hipHostMallocCoherent));
+    if (!ctx->finish_ticket) {
+        HIP_TRY(hipMalloc((void**)&ctx->finish_ticket, 64));
+        HIP_TRY(hipMemsetAsync(ctx->finish_ticket, 0, 64, ctx->stream));
+    }
+    ctx->armed_seq = ++ctx->round_seq;
+    return RoundPublish{ctx->finish_ticket, ctx->round_flag, ctx->armed_seq};
+}
 // copy k small results to the host.  Round results are written by the finishing kernel straight into pinned (device-visible) host
 // memory (d == the pinned slot): nothing to copy, only the stream to drain, ~270 times per grand product; anything else is copied
 // into the pinned slot first.
 static void fetch_fe(cozk_ctx* ctx, const fe* d, size_t k, fe* h) {
     fe* pin = (fe*)ctx_pinned(ctx, k * sizeof(fe));
-    if (d != pin) HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
-    stream_drain_by_flag(ctx);
+    const uint32_t armed = ctx->armed_seq;
+    ctx->armed_seq = 0;
+    if (d == pin && armed) {  // the finishing kernel publishes the sequence number itself
+        volatile uint32_t* f = ctx->round_flag;
+        uint64_t spins = 0;
+        while (*f != armed) {
+            __builtin_ia32_pause();
+            if (++spins > (1ull << 22)) {  // ~10 ms without news: the blocking wait also surfaces launch errors
+                HIP_TRY(hipStreamSynchronize(ctx->stream));
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        if (d != pin) HIP_TRY(hipMemcpyAsync(pin, d, k * sizeof(fe), hipMemcpyDeviceToHost, ctx->stream));
+        stream_drain_by_flag(ctx);
+    }
     for (size_t i = 0; i < k; i++) h[i] = pin[i];
 }
 // where a finishing kernel should put k round results (pinned host memory, mapped into the device)
@@ -1506,7 +1550,7 @@ int cozk_poly_batch_evaluate_at_chi(cozk_ctx* ctx, const cozk_poly* const* polys
             if (mode == COZK_MODE_REP3) k_poly_eval_chi<2><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, (int)k, partial);
             else k_poly_eval_chi<1><<<grid, PT, 0, ctx->stream>>>(da, db, dl, (const fe*)chi->d, (int)k, partial);
         }
-        k_finish_sums<<<(unsigned)k, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
+        k_finish_sums<<<(unsigned)k, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         std::vector<fe> h(k);
         fetch_fe(ctx, res, k, h.data());
@@ -1526,7 +1570,7 @@ int cozk_poly_dot_product_with_public(cozk_ctx* ctx, const cozk_poly* p, const c
         int nc = p->mode == COZK_MODE_REP3 ? 2 : 1;
         if (nc == 2) k_poly_dot_public<2><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
         else k_poly_dot_public<1><<<gx, PT, 0, ctx->stream>>>(poly_a(p), poly_b(p), (const fe*)pub->d, p->len, partial);
-        k_finish_sums<<<nc, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        k_finish_sums<<<nc, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         fe h[2];
         fetch_fe(ctx, res, nc, h);
@@ -1742,7 +1786,7 @@ int cozk_open_quadratic_evals(cozk_ctx* ctx, const cozk_poly* const* polys, cons
             if (mode == COZK_MODE_REP3) k_open_quadratic<2><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
             else k_open_quadratic<1><<<grid, PT, 0, ctx->stream>>>(da, db, de, dh, partial);
         }
-        k_finish_sums<<<(unsigned)(2 * k), PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res);
+        k_finish_sums<<<(unsigned)(2 * k), PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), mode == COZK_MODE_REP3 ? 1 : 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         std::vector<fe> h(2 * k);
         fetch_fe(ctx, res, 2 * k, h.data());
@@ -1787,7 +1831,7 @@ int cozk_prod_sumcheck_evals(cozk_ctx* ctx, const cozk_poly* const* polys, size_
             switch (m) { case 1: PROD_LAUNCH(1, 1); break; case 2: PROD_LAUNCH(1, 2); break; case 3: PROD_LAUNCH(1, 3); break; default: PROD_LAUNCH(1, 4); }
         }
 #undef PROD_LAUNCH
-        k_finish_sums<<<(unsigned)degree, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), shared >= 0 ? 1 : 0, res);
+        k_finish_sums<<<(unsigned)degree, PT, 0, ctx->stream>>>(partial, gx, fr_two_inv(), shared >= 0 ? 1 : 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         fe h[4];
         fetch_fe(ctx, res, (size_t)degree, h);
@@ -1813,7 +1857,7 @@ int cozk_spartan_first_round(cozk_ctx* ctx, const cozk_poly* za, const cozk_poly
             k_spartan_first<2><<<gx, PT, 0, ctx->stream>>>(poly_a(za), poly_b(za), poly_a(zb), poly_b(zb), poly_a(zc), poly_b(zc), poly_a(pub), half, partial);
         else
             k_spartan_first<1><<<gx, PT, 0, ctx->stream>>>(poly_a(za), nullptr, poly_a(zb), nullptr, poly_a(zc), nullptr, poly_a(pub), half, partial);
-        k_finish_sums<<<8, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        k_finish_sums<<<8, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         fe h[8];
         fetch_fe(ctx, res, 8, h);
@@ -1842,7 +1886,7 @@ int cozk_spartan_second_round(cozk_ctx* ctx, const cozk_poly* z, const cozk_poly
         fe c0 = fe_from_u64x4(coef), c1 = fe_from_u64x4(coef + 4), c2 = fe_from_u64x4(coef + 8);
         if (nc == 2) k_spartan_second<2><<<gx, PT, 0, ctx->stream>>>(poly_a(z), poly_b(z), poly_a(a), poly_a(b), poly_a(c), c0, c1, c2, half, partial);
         else k_spartan_second<1><<<gx, PT, 0, ctx->stream>>>(poly_a(z), nullptr, poly_a(a), poly_a(b), poly_a(c), c0, c1, c2, half, partial);
-        k_finish_sums<<<(unsigned)(3 * nc), PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+        k_finish_sums<<<(unsigned)(3 * nc), PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res, arm_round_publish(ctx));
         HIP_TRY(hipGetLastError());
         fe h[6];
         fetch_fe(ctx, res, (size_t)(3 * nc), h);
@@ -2135,7 +2179,7 @@ static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
         if (nested) k_layer_cubic<1, 1><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, eq->E1_len / 2, E2, eq->E2_len, partial);
         else k_layer_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(a, b, l->len, E1, 0, E2, eq->E2_len, partial);
     }
-    k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+    k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res, arm_round_publish(ctx));
     HIP_TRY(hipGetLastError());
     fetch_fe(ctx, res, 3, s);
 }
@@ -2221,7 +2265,7 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
                 else k_layer_bind_cubic<1, 0><<<gx, PT, 0, ctx->stream>>>(ia, nullptr, oa, nullptr, l->len, rr, E1, 0, E2, e->E2_len, partial);
             }
             }
-            k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res);
+            k_finish_sums<<<3, PT, 0, ctx->stream>>>(partial, gx, Fr::one(), 0, res, arm_round_publish(ctx));
             HIP_TRY(hipGetLastError());
             l->cur = dst;
             l->len = nout;
