@@ -778,7 +778,7 @@ static int resident_timeout_s() {
 }
 static constexpr size_t ROUND_PERSIST_MAX = 2048;
 
-template <int NC>
+template <int NC, int TRACE>
 __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0, fe* la1, fe* lb1, int lcur, size_t len, fe* e1_0, fe* e1_1,
                                                              int c1, size_t E1_len, fe* e2_0, fe* e2_1, int c2, size_t E2_len, int nrounds,
                                                              int bind_first, fe r_first, RoundMailbox* mb, long long timeout_ticks) {
@@ -790,12 +790,12 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
     fe* e1[2] = {e1_0, e1_1};
     fe* e2[2] = {e2_0, e2_1};
     uint32_t seq = 0;
-    long long tk0 = wall_clock64(), tk_wait = 0, tk_bind = 0, tk_cubic = 0, tk_pub = 0;
+    long long tk0 = TRACE ? wall_clock64() : 0, tk_wait = 0, tk_bind = 0, tk_cubic = 0, tk_pub = 0;  // TRACE: per-phase device times (COZK_TRACE_ROUNDS)
     // rounds 0 .. nrounds-1 publish cubic sums; "round" nrounds only binds and publishes the final claims
     for (int round = 0; round <= nrounds; round++) {
         bool do_bind = round > 0 || bind_first;
         fe r = r_first;
-        tk0 = wall_clock64();
+        if (TRACE) tk0 = wall_clock64();
         if (round > 0) {
             if (threadIdx.x == 0) {
                 long long t0 = wall_clock64();
@@ -821,7 +821,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
             if (!sh_ok) return;  // uniform: every wave reads the same shared word after the barrier
             r = sh_r;
         }
-        {
+        if (TRACE) {
             long long t = wall_clock64();
             tk_wait += t - tk0;
             tk0 = t;
@@ -870,7 +870,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
             }
         }
         seq++;
-        {
+        if (TRACE) {
             long long t = wall_clock64();
             tk_bind += t - tk0;
             tk0 = t;
@@ -940,7 +940,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
         __syncthreads();
         if ((threadIdx.x & 63) == 0) sh16[wave] = acc;
         __syncthreads();
-        {
+        if (TRACE) {
             long long t = wall_clock64();
             tk_cubic += t - tk0;
             tk0 = t;
@@ -953,7 +953,7 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
         }
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_store(&mb->res_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        {
+        if (TRACE) {
             long long t = wall_clock64();
             tk_pub += t - tk0;
             tk0 = t;
@@ -2409,12 +2409,18 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
             std::atomic_thread_fence(std::memory_order_seq_cst);
             fe r_first = have_r ? fe_from_u64x4(rr) : Fr::zero();
             const long long ticks = (long long)resident_timeout_s() * MB_TICKS_PER_S;
-            if (l->mode == COZK_MODE_REP3)
-                k_layer_rounds_persistent<2><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], l->buf[0][1], l->buf[1][0], l->buf[1][1], l->cur, l->len, e->E1[0], e->E1[1],
-                                                                       e->c1, e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
-            else
-                k_layer_rounds_persistent<1><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], nullptr, l->buf[1][0], nullptr, l->cur, l->len, e->E1[0], e->E1[1], e->c1,
-                                                                       e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks);
+            static const bool trace = getenv("COZK_TRACE_ROUNDS") != nullptr;  // the traced variant reads the 100 MHz clock four times per round
+#define COZK_RESIDENT(NC_, TR_, LB0_, LB1_)                                                                                                          \
+    k_layer_rounds_persistent<NC_, TR_><<<1, RT, 0, ctx->stream>>>(l->buf[0][0], LB0_, l->buf[1][0], LB1_, l->cur, l->len, e->E1[0], e->E1[1], e->c1, \
+                                                                   e->E1_len, e->E2[0], e->E2[1], e->c2, e->E2_len, nrem, have_r ? 1 : 0, r_first, mb, ticks)
+            if (l->mode == COZK_MODE_REP3) {
+                if (trace) COZK_RESIDENT(2, 1, l->buf[0][1], l->buf[1][1]);
+                else COZK_RESIDENT(2, 0, l->buf[0][1], l->buf[1][1]);
+            } else {
+                if (trace) COZK_RESIDENT(1, 1, nullptr, nullptr);
+                else COZK_RESIDENT(1, 0, nullptr, nullptr);
+            }
+#undef COZK_RESIDENT
             HIP_TRY(hipGetLastError());
             volatile uint32_t* res_seq = &mb->res_seq;
             volatile uint32_t* status = &mb->status;
