@@ -11,6 +11,7 @@
 // mpc-core/src/protocols/rep3/arithmetic.rs:144-164).
 #pragma once
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -49,47 +50,37 @@ struct Abort {
     std::atomic<bool> flag{false};
 };
 
+// One producer, one consumer (every channel here is: worker -> coordinator, coordinator -> worker, party -> next party): a ring of
+// slots with two counters, no lock.  A sumcheck round is a ~20 us ping-pong between a worker and the coordinator and a chained proof
+// has ~1660 of them; the mutex + deque + condition variable this replaces measured 2.5-7 us per round trip (the consumer saw the
+// count rise inside the producer's critical section and then waited for its mutex).
 template <class T>
 struct Chan {
-    std::mutex m;
-    std::condition_variable cv;
-    std::deque<T> q;
-    std::atomic<int> n_queued{0};  // lets pop() poll without taking the mutex
+    static constexpr size_t CAP = 1024;  // messages in flight per direction are a handful (request / response protocols)
+    std::vector<T> slots = std::vector<T>(CAP);
+    alignas(64) std::atomic<size_t> head{0};  // next slot to pop (written by the consumer)
+    alignas(64) std::atomic<size_t> tail{0};  // next slot to fill (written by the producer)
     Abort* abort = nullptr;
+    void wait_step(int& spin) {
+        // busy-poll first (a sched_yield per probe costs microseconds on a loaded host, a sleep tens), then yield, then sleep
+        if ((++spin & 1023) == 0 && abort && abort->flag.load()) throw CozkError(COZK_ERR_INTERNAL, "aborted: a peer failed");
+        if (spin < 40000) __builtin_ia32_pause();
+        else if (spin < 60000) std::this_thread::yield();
+        else std::this_thread::sleep_for(std::chrono::microseconds(200));
+    }
     void push(T v) {
-        {
-            std::lock_guard<std::mutex> g(m);
-            q.push_back(std::move(v));
-            n_queued.fetch_add(1, std::memory_order_release);
-        }
-        cv.notify_all();
+        const size_t t = tail.load(std::memory_order_relaxed);
+        int spin = 0;
+        while (t - head.load(std::memory_order_acquire) >= CAP) wait_step(spin);
+        slots[t % CAP] = std::move(v);
+        tail.store(t + 1, std::memory_order_release);
     }
     T pop() {
-        // a sumcheck round is a ~30 us ping-pong between a worker and the coordinator: busy-poll first (a
-        // sched_yield per probe costs microseconds on a loaded host, a futex sleep/wake-up tens), then yield,
-        // then sleep
-        for (int spin = 0; spin < 60000; spin++) {
-            if (n_queued.load(std::memory_order_acquire) > 0) {
-                std::lock_guard<std::mutex> g(m);
-                if (!q.empty()) {
-                    T v = std::move(q.front());
-                    q.pop_front();
-                    n_queued.fetch_sub(1, std::memory_order_relaxed);
-                    return v;
-                }
-            }
-            if ((spin & 1023) == 1023 && abort && abort->flag.load()) throw CozkError(COZK_ERR_INTERNAL, "aborted: a peer failed");
-            if (spin < 40000) __builtin_ia32_pause();
-            else std::this_thread::yield();
-        }
-        std::unique_lock<std::mutex> g(m);
-        while (q.empty()) {
-            if (abort && abort->flag.load()) throw CozkError(COZK_ERR_INTERNAL, "aborted: a peer failed");
-            cv.wait_for(g, std::chrono::milliseconds(50));
-        }
-        T v = std::move(q.front());
-        q.pop_front();
-        n_queued.fetch_sub(1, std::memory_order_relaxed);
+        const size_t h = head.load(std::memory_order_relaxed);
+        int spin = 0;
+        while (tail.load(std::memory_order_acquire) == h) wait_step(spin);
+        T v = std::move(slots[h % CAP]);
+        head.store(h + 1, std::memory_order_release);
         return v;
     }
 };
