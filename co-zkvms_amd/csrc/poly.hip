@@ -751,17 +751,18 @@ __global__ void __launch_bounds__(RT) k_layer_round_small(const fe* __restrict__
 // A launch-and-drain costs ~38 us on this platform however small the kernel (measured per round, 2^3 .. 2^19
 // elements alike), and a grand product has ~170 rounds on layers of <= 2048 elements.  For those tails ONE
 // single-workgroup kernel stays resident for all remaining rounds of the layer's sumcheck and talks to the host
-// through a mailbox in fine-grained pinned memory: it publishes the three cubic sums of a round, spins (lane 0
+// through a mailbox in fine-grained pinned memory: it publishes the three cubic sums of a round, spins (wave 0
 // only; the other waves sit at the barrier) until the host has posted the challenge, binds layer + eq tables,
 // and goes on -- a PCIe round trip (~3 us) per round instead of a launch.  After the last challenge it binds once
 // more and publishes the final claims.  Every wait is bounded by the wall clock (resident_timeout_s() seconds of the
 // 100 MHz counter): a host that never answers makes the kernel raise `status` and return, so the grid always drains.
 struct alignas(64) RoundMailbox {
-    uint32_t cmd_seq;  // host -> device: challenge number k has been posted (k = 1, 2, ...)
-    uint32_t abort;    // host -> device: give up
-    uint32_t pad0[14];
-    fe r;              // host -> device: the challenge
-    uint32_t pad1[8];
+    // host -> device, ONE 64-byte line read by one load instruction (four lanes x 16 B = one PCIe read instead of a poll of the
+    // sequence number followed by a read of the challenge): pieces 0..2 = three limbs of the challenge + the challenge's number
+    // as a tag in their last word (a 16-byte piece is read whole, the host writes its tag last, so a piece whose tag matches
+    // carries its payload), piece 3 = the abort word
+    uint32_t cmd[16];
+    uint32_t pad0[16];
     uint32_t res_seq;  // device -> host: result number k is ready
     uint32_t status;   // device -> host: 0 ok, 1 timed out waiting for the host, 2 aborted
     uint32_t pad2[14];
@@ -797,25 +798,37 @@ __global__ void __launch_bounds__(RT) k_layer_rounds_persistent(fe* la0, fe* lb0
         fe r = r_first;
         if (TRACE) tk0 = wall_clock64();
         if (round > 0) {
-            if (threadIdx.x == 0) {
-                long long t0 = wall_clock64();
+            if (threadIdx.x < 64) {  // wave 0 polls: lanes 0..3 read one 16-byte piece of the command line each
+                typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+                const int lane = threadIdx.x;
+                const long long t0 = wall_clock64();
                 int ok = 1;
+                v4u v = {0u, 0u, 0u, 0u};
                 for (;;) {
-                    if (__hip_atomic_load(&mb->cmd_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) == (uint32_t)round) break;
-                    if (__hip_atomic_load(&mb->abort, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)) {
+                    if (lane < 4) v = *reinterpret_cast<volatile v4u*>(&mb->cmd[4 * lane]);
+                    const unsigned long long ready = __ballot(lane < 3 && v.w == (uint32_t)round);
+                    const unsigned long long aborted = __ballot(lane == 3 && v.x != 0u);
+                    if ((ready & 7ull) == 7ull) break;
+                    if (aborted) {
                         ok = 0;
-                        __hip_atomic_store(&mb->status, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (lane == 0) __hip_atomic_store(&mb->status, 2u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
-                    if (wall_clock64() - t0 > timeout_ticks) {
+                    if (__shfl((int)(wall_clock64() - t0 > timeout_ticks), 0)) {  // lane 0's clock decides for the wave
                         ok = 0;
-                        __hip_atomic_store(&mb->status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                        if (lane == 0) __hip_atomic_store(&mb->status, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                         break;
                     }
                     __builtin_amdgcn_s_sleep(2);
                 }
-                if (ok) sh_r = fe_load(&mb->r);  // two 16-byte loads behind the acquire: one PCIe round trip, not eight
-                sh_ok = ok;
+                fe rr;
+                rr.l[0] = __shfl(v.x, 0); rr.l[1] = __shfl(v.y, 0); rr.l[2] = __shfl(v.z, 0);
+                rr.l[3] = __shfl(v.x, 1); rr.l[4] = __shfl(v.y, 1); rr.l[5] = __shfl(v.z, 1);
+                rr.l[6] = __shfl(v.x, 2); rr.l[7] = __shfl(v.y, 2);
+                if (lane == 0) {
+                    if (ok) sh_r = rr;
+                    sh_ok = ok;
+                }
             }
             __syncthreads();
             if (!sh_ok) return;  // uniform: every wave reads the same shared word after the barrier
@@ -2427,7 +2440,7 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
             volatile uint32_t* res_seq = &mb->res_seq;
             volatile uint32_t* status = &mb->status;
             auto give_up = [&](const char* why) {
-                *(volatile uint32_t*)&mb->abort = 1;
+                *(volatile uint32_t*)&mb->cmd[12] = 1;
                 std::atomic_thread_fence(std::memory_order_seq_cst);
                 (void)hipStreamSynchronize(ctx->stream);
                 throw CozkError(COZK_ERR_INTERNAL, why);
@@ -2474,9 +2487,18 @@ int cozk_layer_prove_rounds(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const
                 memcpy(out_r + 4 * (round + j), rr, sizeof rr);
                 memcpy(pc, nc, sizeof pc);
                 have_r = true;
-                mb->r = fe_from_u64x4(rr);
-                std::atomic_thread_fence(std::memory_order_release);
-                *(volatile uint32_t*)&mb->cmd_seq = (uint32_t)j + 1;
+                {
+                    // three self-validating pieces: payload first, then the half that carries the tag (x86 stores stay in order)
+                    const fe rv = fe_from_u64x4(rr);
+                    const uint32_t tag = (uint32_t)j + 1;
+                    const uint32_t pay[9] = {rv.l[0], rv.l[1], rv.l[2], rv.l[3], rv.l[4], rv.l[5], rv.l[6], rv.l[7], 0u};
+                    for (int k = 0; k < 3; k++) {
+                        volatile uint64_t* piece = reinterpret_cast<volatile uint64_t*>(&mb->cmd[4 * k]);
+                        piece[0] = (uint64_t)pay[3 * k] | ((uint64_t)pay[3 * k + 1] << 32);
+                        std::atomic_thread_fence(std::memory_order_release);
+                        piece[1] = (uint64_t)pay[3 * k + 2] | ((uint64_t)tag << 32);
+                    }
+                }
             }
             if (alive) alive = wait_result((uint32_t)nrem + 1);
             if (!alive) {
