@@ -69,6 +69,7 @@ SIGNATURES = {
     "cozk_ctx_synchronize": (_i, [_vp]),
     "cozk_ctx_stream": (_i, [_vp, _pp]),
     "cozk_vec_upload": (_i, [_vp, _vp, _sz, _i, _pp]),
+    "cozk_vec_narrow": (_i, [_vp, _vp, _i, _pp]),
     "cozk_vec_alloc": (_i, [_vp, _sz, _i, _pp]),
     "cozk_vec_download": (_i, [_vp, _vp, _vp]),
     "cozk_vec_free": (_i, [_vp]),

@@ -112,6 +112,17 @@ __global__ void __launch_bounds__(256) k_bench_montmul(fe* x, int iters) {
     fe_store(x + i, a);
 }
 
+template <typename T>
+__global__ void k_vec_narrow(const fe* __restrict__ in, T* __restrict__ out, size_t n, unsigned* __restrict__ bad) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const fe v = Fr::from_mont(fe_load(in + i));
+    uint32_t high = 0;
+    for (int k = (int)(sizeof(T) / 4); k < 8; k++) high |= v.l[k];
+    if (high) atomicOr(bad, 1u);
+    out[i] = sizeof(T) == 4 ? (T)v.l[0] : (T)((uint64_t)v.l[0] | ((uint64_t)v.l[1] << 32));
+}
+
 extern "C" {
 
 int cozk_device_count(int* out) {
@@ -216,6 +227,39 @@ int cozk_vec_upload(cozk_ctx* ctx, const void* host, size_t n, int kind, cozk_ve
             HIP_TRY(hipStreamSynchronize(ctx->stream));
         }
     });
+}
+
+int cozk_vec_narrow(cozk_ctx* ctx, const cozk_vec* fr, int kind, cozk_vec** out) {
+    if (!out) return COZK_ERR_INVALID_ARG;
+    *out = nullptr;
+    int rc = cozk_guard(ctx, [&] {
+        COZK_REQUIRE(ctx && fr && fr->kind == COZK_SCALAR_FR && (kind == COZK_SCALAR_U32 || kind == COZK_SCALAR_U64), "vec_narrow: an FR vector and U32 / U64");
+    });
+    if (rc != COZK_OK) return rc;
+    rc = cozk_vec_alloc(ctx, fr->n, kind, out);
+    if (rc != COZK_OK) return rc;
+    unsigned bad = 0;
+    rc = cozk_guard(ctx, [&] {
+        if (fr->n == 0) return;
+        ctx->scratch2.reserve(64);
+        unsigned* d_bad = (unsigned*)ctx->scratch2.p;
+        HIP_TRY(hipMemsetAsync(d_bad, 0, sizeof(unsigned), ctx->stream));
+        const unsigned grid = (unsigned)((fr->n + 255) / 256);
+        if (kind == COZK_SCALAR_U32) k_vec_narrow<uint32_t><<<grid, 256, 0, ctx->stream>>>((const fe*)fr->d, (uint32_t*)(*out)->d, fr->n, d_bad);
+        else k_vec_narrow<uint64_t><<<grid, 256, 0, ctx->stream>>>((const fe*)fr->d, (uint64_t*)(*out)->d, fr->n, d_bad);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(hipStreamSynchronize(ctx->stream));
+    });
+    if (rc == COZK_OK && bad) {
+        ctx->last_error = "vec_narrow: a value does not fit the requested kind";
+        rc = COZK_ERR_INVALID_ARG;
+    }
+    if (rc != COZK_OK) {
+        cozk_vec_free(*out);
+        *out = nullptr;
+    }
+    return rc;
 }
 
 int cozk_vec_download(cozk_ctx* ctx, const cozk_vec* v, void* host) {

@@ -47,6 +47,8 @@ struct FlowParty {
     int party = 0;
     std::vector<PolyH> polys;       // evaluation view (REP3 shares, or PLAIN Fr values for public polynomials), commit order
     std::vector<VecH> commit_vecs;  // what the MSM and the fingerprints consume: share-a view, or the compact public column
+    std::vector<VecH> msm_vecs;     // PLAIN mode: a narrow (U32 / U64) copy of a secret column whose values fit, for the MSM only
+                                    // (msm_field_elements' dispatch on the scalars' bit length); empty handle = commit_vecs[i]
     std::unique_ptr<PST13Setup> setup;
     VecH iota;                         // 0, 1, 2, .. as U32 (identity / index columns of the leaves)
     std::vector<VecH> bc_table;        // the bytecode table (preprocessing.v_init_final): 6 compact columns of B entries
@@ -288,6 +290,13 @@ void flow_setup_party(cozk_flow* h, FlowParty& ps) {
             cozk_vec* view = nullptr;
             rc_check(cozk_poly_share_view(ctx, p, 0, &view), ctx, "share_view");
             ps.commit_vecs.push_back(VecH(view));
+            ps.msm_vecs.emplace_back();
+            const int bits = h->device_bits[(size_t)idx];
+            if (c.mode == COZK_MODE_PLAIN && bits > 0 && bits <= 64) {  // masked by construction; cozk_vec_narrow checks it anyway
+                cozk_vec* nv = nullptr;
+                rc_check(cozk_vec_narrow(ctx, view, bits <= 32 ? COZK_SCALAR_U32 : COZK_SCALAR_U64, &nv), ctx, "vec_narrow");
+                ps.msm_vecs.back() = VecH(nv);
+            }
             continue;
         }
         const std::vector<fe>& col = h->clear[(size_t)idx];
@@ -304,6 +313,7 @@ void flow_setup_party(cozk_flow* h, FlowParty& ps) {
                 ints[i] = (uint64_t)v.l[0] | ((uint64_t)v.l[1] << 32);
             }
             ps.commit_vecs.push_back(flow_upload_compact(ctx, ints, h->pub_bytes[(size_t)idx]));
+            ps.msm_vecs.emplace_back();
         } else {
             if (c.mode == COZK_MODE_PLAIN) {
                 rc_check(cozk_poly_create(ctx, COZK_MODE_PLAIN, plain.h, nullptr, &p), ctx, "poly_create");
@@ -321,6 +331,18 @@ void flow_setup_party(cozk_flow* h, FlowParty& ps) {
             cozk_vec* view = nullptr;
             rc_check(cozk_poly_share_view(ctx, p, 0, &view), ctx, "share_view");
             ps.commit_vecs.push_back(VecH(view));
+            ps.msm_vecs.emplace_back();
+            if (c.mode == COZK_MODE_PLAIN) {  // a secret column of a plain prover: as wide as its values (the host has them in the clear)
+                uint32_t hi32 = 0, hi64 = 0;
+                std::vector<uint64_t> ints(col.size());
+                for (size_t i = 0; i < col.size(); i++) {
+                    const fe v = Fr::from_mont(col[i]);
+                    hi32 |= v.l[1];
+                    for (int k = 2; k < 8; k++) hi64 |= v.l[k];
+                    ints[i] = (uint64_t)v.l[0] | ((uint64_t)v.l[1] << 32);
+                }
+                if (!hi64) ps.msm_vecs.back() = flow_upload_compact(ctx, ints, (hi32 | hi64) ? 8 : 4);
+            }
         }
     }
     size_t imax = std::max(std::max(h->N, h->M), std::max(h->B, h->MEM));
@@ -480,7 +502,7 @@ void flow_worker_main(cozk_flow* h, FlowParty& ps, StarNetWorker* star, RingNet*
     // ---- 1. commit-all: every party MSMs every polynomial; only P0's public commitments are kept (pst13.rs:165-229)
     {
         std::vector<cozk_vec*> vs;
-        for (auto& v : ps.commit_vecs) vs.push_back(v.h);
+        for (size_t i = 0; i < ps.commit_vecs.size(); i++) vs.push_back(ps.msm_vecs[i].h ? ps.msm_vecs[i].h : ps.commit_vecs[i].h);
         std::vector<PST13Commitment> cm = PST13::batch_commit(ps.ctx, *ps.setup, vs);
         Writer w;
         put_commitments(w, cm, h->is_public, ps.party);
@@ -1096,6 +1118,7 @@ int cozk_flow_destroy(cozk_flow* h) {
         if (ps.ctx) (void)hipSetDevice(ps.ctx->device);
         ps.polys.clear();
         ps.commit_vecs.clear();
+        ps.msm_vecs.clear();
         ps.setup.reset();
         ps.iota = VecH();
         ps.bc_table.clear();

@@ -250,6 +250,13 @@ class Vec:
             return mont_limbs_to_int(a)
         return [int(x) for x in a]
 
+    def narrow(self, kind):
+        """this FR vector as a U32 / U64 vector of the same values (cozk_vec_narrow: what msm_field_elements' dispatch on the scalars'
+        bit length amounts to); raises CozkError if a value does not fit"""
+        h = ctypes.c_void_p()
+        self.ctx.check(self.ctx._l.cozk_vec_narrow(self.ctx.h, self.h, kind, ctypes.byref(h)))
+        return Vec(self.ctx, h, kind)
+
     def rep3_share(self, key0, key1, party, counter=0):
         """Rep3 shares (a, b) of this secret vector for `party` (cozk_rep3_share_vec); key0 / key1 = 32-byte PRF keys"""
         a, b = ctypes.c_void_p(), ctypes.c_void_p()

@@ -79,6 +79,11 @@ int cozk_device_count(int* out);
 /* ---------------------------------------------------------------- device vectors ---------- */
 /* upload a scalar vector (kind = COZK_SCALAR_*); `host` holds n elements of that kind */
 int cozk_vec_upload(cozk_ctx* ctx, const void* host, size_t n, int kind, cozk_vec** out);
+/* An FR vector whose canonical values fit `kind` (COZK_SCALAR_U32 / COZK_SCALAR_U64) as a vector of that kind -- what
+ * VariableBaseMSM::msm_field_elements does before it dispatches on the scalars' bit length (jolt-core msm; call site
+ * co-jolt/src/poly/commitment/pst13.rs:286-294): the MSM then sorts 3 / 5 windows of a 4- / 8-byte scalar instead of 16 of a
+ * 32-byte one.  COZK_ERR_INVALID_ARG (and no vector) if any value does not fit. */
+int cozk_vec_narrow(cozk_ctx* ctx, const cozk_vec* fr, int kind, cozk_vec** out);
 int cozk_vec_alloc(cozk_ctx* ctx, size_t n, int kind, cozk_vec** out);
 int cozk_vec_download(cozk_ctx* ctx, const cozk_vec* v, void* host);
 int cozk_vec_free(cozk_vec* v);

@@ -73,6 +73,31 @@ def test_msm_infinity_repeats_and_cancellation(cozk, ctx):
     assert B.msm(cozk.Vec.from_ints(ctx, [0] * len(pts))) is None
 
 
+@pytest.mark.parametrize("kind,bits", [("U32", 32), ("U32", 20), ("U64", 64), ("U64", 33)])
+def test_vec_narrow_keeps_values_and_the_commitment(cozk, ctx, kind, bits):
+    """cozk_vec_narrow (msm_field_elements' dispatch on the scalars' bit length, pst13.rs:286-294): an FR vector of small values as a
+    U32 / U64 vector -- same values, same MSM result; a value that does not fit is refused"""
+    n = 600
+    rng = O.SplitMix64(900 + bits)
+    vals = [rng.field() & ((1 << bits) - 1) for _ in range(n)]
+    vals[0], vals[1], vals[2] = 0, (1 << bits) - 1, 1
+    v = cozk.Vec.from_ints(ctx, vals)
+    k = getattr(cozk, "SCALAR_" + kind)
+    nv = v.narrow(k)
+    assert nv.to_ints() == vals
+    pts = _bases(rng, n)
+    B = cozk.Bases.upload(ctx, pts, precompute=True)
+    assert B.msm(nv) == B.msm(v) == O.msm_naive(pts, vals)
+    width = 32 if kind == "U32" else 64
+    bad = list(vals)
+    bad[n // 2] = 1 << width
+    with pytest.raises(cozk.CozkError):
+        cozk.Vec.from_ints(ctx, bad).narrow(k)
+    bad[n // 2] = O.R - 1
+    with pytest.raises(cozk.CozkError):
+        cozk.Vec.from_ints(ctx, bad).narrow(k)
+
+
 @pytest.mark.parametrize("kind,bits", [("U8", 8), ("U16", 16), ("U32", 32), ("U64", 64), ("U8", 1)])
 def test_msm_small_scalar_kinds(cozk, ctx, kind, bits):
     n = 700
