@@ -495,12 +495,37 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic(const fe* __restrict__ 
 
 // ---- the layer kernels on the 9 x 29 multiplier (round 3, fr9.hip.hpp): same thread mapping and tails as k_layer_cubic /
 // k_layer_bind_cubic, every product on the fused 29-bit chains, additions lazy, one lambda-removing product per lane at the end.
-// terms of one output chunk: s_k += (l_k x r_k) e_k [E2 factor folded into the eq pair first] at X = 0, 2, 3
+// terms of one output chunk: s_k += (l_k x r_k) e_k at X = 0, 2, 3.  NESTED = 1: the E2 factor is folded into the eq pair first (two
+// products per chunk).  NESTED = 2 (E1 tables of >= 512 pairs; the launcher walks the chunks block-contiguously): the inner sums of
+// the split-eq form -- the terms of the chunks that share one E2 entry are summed with the raw E1 pair (lambda^2) in `grp` and
+// multiplied by E2[x2] once per group (three products per E1_half / 256 chunks instead of two per chunk), as the reference's
+// nested loops do (dense_interleaved_poly.rs:230-300).
+struct Layer9Group {
+    f9 g0, g2, g3;
+    size_t x2;
+};
+static __device__ __forceinline__ void layer9_group_flush(Layer9Group& grp, const fe* __restrict__ E2, f9& s0, f9& s2, f9& s3) {
+    if (grp.x2 == (size_t)-1) return;
+    const f9 sc = f9_from_fe(fe_load(E2 + grp.x2));
+    s0 = f9_norm(fr9_add(s0, fr9_mul(grp.g0, sc)));
+    s2 = f9_norm(fr9_add(s2, fr9_mul(grp.g2, sc)));
+    s3 = f9_norm(fr9_add(s3, fr9_mul(grp.g3, sc)));
+}
 template <int NC, int NESTED>
 static __device__ __forceinline__ void layer9_terms(const Sh9<NC>& l0, const Sh9<NC>& r0, const Sh9<NC>& l1, const Sh9<NC>& r1, const fe* __restrict__ E1,
-                                                    size_t E1_half, int e1_shift, const fe* __restrict__ E2, size_t c, f9& s0, f9& s2, f9& s3) {
+                                                    size_t E1_half, int e1_shift, const fe* __restrict__ E2, size_t c, f9& s0, f9& s2, f9& s3,
+                                                    Layer9Group& grp) {
     f9 e0, e1;
-    if (NESTED) {
+    if (NESTED == 2) {
+        const size_t x2 = c >> e1_shift, x1 = c & (E1_half - 1);
+        if (x2 != grp.x2) {
+            layer9_group_flush(grp, E2, s0, s2, s3);
+            grp.g0 = grp.g2 = grp.g3 = fr9_zero();
+            grp.x2 = x2;
+        }
+        e0 = f9_from_fe(fe_load(E1 + 2 * x1));
+        e1 = f9_from_fe(fe_load(E1 + 2 * x1 + 1));
+    } else if (NESTED) {
         const size_t x2 = c >> e1_shift, x1 = c & (E1_half - 1);
         const f9 sc = f9_from_fe(fe_load(E2 + x2));
         e0 = fr9_mul(f9_from_fe(fe_load(E1 + 2 * x1)), sc);
@@ -514,9 +539,26 @@ static __device__ __forceinline__ void layer9_terms(const Sh9<NC>& l0, const Sh9
     const Sh9<NC> ml = sh9_diff<NC>(l1, l0), mr = sh9_diff<NC>(r1, r0);
     const Sh9<NC> l2 = sh9_add_norm<NC>(l1, ml), r2 = sh9_add_norm<NC>(r1, mr);
     const Sh9<NC> l3 = sh9_add_norm<NC>(l2, ml), r3 = sh9_add_norm<NC>(r2, mr);
-    s0 = f9_norm(fr9_add(s0, fr9_mul(e0, sh9_local_mul<NC>(l0, r0))));
-    s2 = f9_norm(fr9_add(s2, fr9_mul(e2, sh9_local_mul<NC>(l2, r2))));
-    s3 = f9_norm(fr9_add(s3, fr9_mul(e3, sh9_local_mul<NC>(l3, r3))));
+    f9& a0 = NESTED == 2 ? grp.g0 : s0;
+    f9& a2 = NESTED == 2 ? grp.g2 : s2;
+    f9& a3 = NESTED == 2 ? grp.g3 : s3;
+    a0 = f9_norm(fr9_add(a0, fr9_mul(e0, sh9_local_mul<NC>(l0, r0))));
+    a2 = f9_norm(fr9_add(a2, fr9_mul(e2, sh9_local_mul<NC>(l2, r2))));
+    a3 = f9_norm(fr9_add(a3, fr9_mul(e3, sh9_local_mul<NC>(l3, r3))));
+}
+// the chunk walk of a workgroup: grid-stride, or (NESTED = 2) one contiguous range per workgroup so that a lane stays inside an E2
+// group for E1_half / 256 iterations; `first` is the wave's first chunk of the first iteration
+static __device__ __forceinline__ void layer9_walk(int nested, size_t nch, size_t& first, size_t& end, size_t& step) {
+    if (nested == 2) {
+        const size_t per = ((nch + gridDim.x - 1) / gridDim.x + PT - 1) / PT * PT;
+        first = (size_t)blockIdx.x * per + (threadIdx.x & ~63u);
+        end = (size_t)(blockIdx.x + 1) * per < nch ? (size_t)(blockIdx.x + 1) * per : nch;
+        step = PT;
+    } else {
+        first = (size_t)blockIdx.x * PT + (threadIdx.x & ~63u);
+        end = nch;
+        step = (size_t)gridDim.x * PT;
+    }
 }
 // lane sums -> canonical R-form block sums in partial[k * gridDim.x + blockIdx.x]
 template <int NESTED>
@@ -588,8 +630,12 @@ __global__ void __launch_bounds__(PT) k_layer_cubic9(const fe* __restrict__ a, c
     if (nch > limit) nch = limit;  // zip() stops at the shorter side
     const int e1_shift = NESTED ? __ffsll((long long)E1_half) - 1 : 0;
     f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
+    Layer9Group grp;
+    grp.x2 = (size_t)-1;
+    size_t c_first, c_end, c_step;
+    layer9_walk(NESTED, nch, c_first, c_end, c_step);
     // the trip count is per WAVE (c0 = the wave's first chunk): a wave whose 64 chunks are all inside the layer takes the staged path
-    for (size_t c0 = (size_t)blockIdx.x * PT + (threadIdx.x & ~63u); c0 < nch; c0 += (size_t)gridDim.x * PT) {
+    for (size_t c0 = c_first; c0 < c_end; c0 += c_step) {
         const size_t c = c0 + (threadIdx.x & 63);
         if (c0 + 64 <= nch && 4 * (c0 + 64) <= len) {
             Sh9<NC> q[4];
@@ -601,13 +647,14 @@ __global__ void __launch_bounds__(PT) k_layer_cubic9(const fe* __restrict__ a, c
 #pragma unroll
                 for (int j = 0; j < 4; j++) q[j].c[k] = f9_from_fe(raw[j]);
             }
-            layer9_terms<NC, NESTED>(q[0], q[1], q[2], q[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+            layer9_terms<NC, NESTED>(q[0], q[1], q[2], q[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3, grp);
         } else if (c < nch) {
             const Sh9<NC> l0 = sh9_load_or_zero<NC>(a, b, 4 * c, len), r0 = sh9_load_or_zero<NC>(a, b, 4 * c + 1, len);
             const Sh9<NC> l1 = sh9_load_or_zero<NC>(a, b, 4 * c + 2, len), r1 = sh9_load_or_zero<NC>(a, b, 4 * c + 3, len);
-            layer9_terms<NC, NESTED>(l0, r0, l1, r1, E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+            layer9_terms<NC, NESTED>(l0, r0, l1, r1, E1, E1_half, e1_shift, E2, c, s0, s2, s3, grp);
         }
     }
+    if (NESTED == 2) layer9_group_flush(grp, E2, s0, s2, s3);
     layer9_finish<NESTED>(s0, s2, s3, partial, sh4);
 }
 
@@ -625,7 +672,11 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic9(const fe* __restrict__
     f9 s0 = fr9_zero(), s2 = fr9_zero(), s3 = fr9_zero();
     __shared__ __attribute__((aligned(16))) char stage[PT / 64][ST_WAVE_BYTES];
     char* st = stage[threadIdx.x >> 6];
-    for (size_t c0 = (size_t)blockIdx.x * PT + (threadIdx.x & ~63u); c0 < nch_out; c0 += (size_t)gridDim.x * PT) {
+    Layer9Group grp;
+    grp.x2 = (size_t)-1;
+    size_t c_first, c_end, c_step;
+    layer9_walk(NESTED, nch_out, c_first, c_end, c_step);
+    for (size_t c0 = c_first; c0 < c_end; c0 += c_step) {
         const size_t c = c0 + (threadIdx.x & 63);
         Sh9<NC> v[4];
         if (c0 + 64 <= nch_out && 8 * (c0 + 64) <= len_in) {
@@ -653,7 +704,7 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic9(const fe* __restrict__
                 for (int j = 0; j < 4; j++) outv[j] = fr9_to_canonical(v[j].c[k]);
                 stage_out_rows(reinterpret_cast<char*>(ocomp[k] + 4 * c0), st, outv);
             }
-            if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+            if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3, grp);
             continue;
         }
         if (c >= nch_out) continue;
@@ -671,8 +722,9 @@ __global__ void __launch_bounds__(PT) k_layer_bind_cubic9(const fe* __restrict__
                 for (int k = 0; k < NC; k++) v[2 * h].c[k] = v[2 * h + 1].c[k] = fr9_zero();
             }
         }
-        if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3);
+        if (c < limit) layer9_terms<NC, NESTED>(v[0], v[1], v[2], v[3], E1, E1_half, e1_shift, E2, c, s0, s2, s3, grp);
     }
+    if (NESTED == 2) layer9_group_flush(grp, E2, s0, s2, s3);
     layer9_finish<NESTED>(s0, s2, s3, partial, sh4);
 }
 
@@ -2179,11 +2231,14 @@ static void layer_cubic_sums(cozk_ctx* ctx, const cozk_layer* l, const cozk_spli
         gx = resident_grid((const void*)k_layer_cubic9<NC_, NE_>, need, dev);                                                        \
         k_layer_cubic9<NC_, NE_><<<gx, PT, 0, ctx->stream>>>(a, B_, l->len, E1, E1H_, E2, eq->E2_len, partial);                      \
     } while (0)
-        if (l->mode == COZK_MODE_REP3) {
+        static const bool group_env = !(getenv("COZK_LAYER_GROUPED") && atoi(getenv("COZK_LAYER_GROUPED")) == 0);
+        const bool grouped = nested && group_env && eq->E1_len / 2 >= 512;  // split-eq inner sums (layer9_terms, NESTED = 2)
+        if (l->mode == COZK_MODE_REP3) {  // (the Rep3 kernels lose with the three group accumulators: 0.58 vs 0.52 ms, register pressure)
             if (nested) COZK_CUBIC9(2, 1, b, eq->E1_len / 2);
             else COZK_CUBIC9(2, 0, b, 0);
         } else {
-            if (nested) COZK_CUBIC9(1, 1, b, eq->E1_len / 2);
+            if (grouped) COZK_CUBIC9(1, 2, b, eq->E1_len / 2);
+            else if (nested) COZK_CUBIC9(1, 1, b, eq->E1_len / 2);
             else COZK_CUBIC9(1, 0, b, 0);
         }
 #undef COZK_CUBIC9
@@ -2264,11 +2319,14 @@ int cozk_layer_round(cozk_ctx* ctx, cozk_layer* l, cozk_spliteq* e, const uint64
         gx = resident_grid((const void*)k_layer_bind_cubic9<NC_, NE_>, need, dev);                                                   \
         k_layer_bind_cubic9<NC_, NE_><<<gx, PT, 0, ctx->stream>>>(ia, IB_, oa, OB_, l->len, r5, E1, E1H_, E2, e->E2_len, partial);   \
     } while (0)
-                if (l->mode == COZK_MODE_REP3) {
+                static const bool group_env = !(getenv("COZK_LAYER_GROUPED") && atoi(getenv("COZK_LAYER_GROUPED")) == 0);
+                const bool grouped = nested && group_env && e->E1_len / 2 >= 512;  // split-eq inner sums (layer9_terms, NESTED = 2)
+                if (l->mode == COZK_MODE_REP3) {  // (plain only: the Rep3 kernels lose with the group accumulators)
                     if (nested) COZK_BIND_CUBIC9(2, 1, ib, ob, e->E1_len / 2);
                     else COZK_BIND_CUBIC9(2, 0, ib, ob, 0);
                 } else {
-                    if (nested) COZK_BIND_CUBIC9(1, 1, nullptr, nullptr, e->E1_len / 2);
+                    if (grouped) COZK_BIND_CUBIC9(1, 2, nullptr, nullptr, e->E1_len / 2);
+                    else if (nested) COZK_BIND_CUBIC9(1, 1, nullptr, nullptr, e->E1_len / 2);
                     else COZK_BIND_CUBIC9(1, 0, nullptr, nullptr, 0);
                 }
 #undef COZK_BIND_CUBIC9
